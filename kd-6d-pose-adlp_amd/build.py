@@ -1,0 +1,71 @@
+"""Build libkd6d.so (gfx950 only) in-tree with hipcc.
+
+Usage: python build.py [--force]
+The shared object lands next to the sources (csrc/libkd6d.so); it is git-ignored but
+travels to the GPU box with the gpurun snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libkd6d.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + ["../../include/kd6d.h"]:
+        path = os.path.join(CSRC, name)
+        if name.endswith((".hip", ".h")) and os.path.isfile(path):
+            with open(path, "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    stamp = os.path.join(CSRC, ".build_stamp")
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == dig:
+                return OUT
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

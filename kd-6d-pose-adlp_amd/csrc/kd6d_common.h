@@ -1,0 +1,103 @@
+// Shared device/host helpers for the kd6d HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/kd6d.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing -------------------------------------------------------
+void kd6d_set_error(const char* fmt, ...);
+
+#define KD6D_CHECK_ARG(cond, ...)              \
+  do {                                         \
+    if (!(cond)) {                             \
+      kd6d_set_error(__VA_ARGS__);             \
+      return KD6D_ERR_ARG;                     \
+    }                                          \
+  } while (0)
+
+#define KD6D_CHECK_LAUNCH(name)                                          \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      kd6d_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return KD6D_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+// ---- scalar conversions ---------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte granule: 8 bf16 or 4 f32.
+template <typename T> struct Granule;
+template <> struct Granule<bf16_t> { static constexpr int N = 8; };
+template <> struct Granule<float> { static constexpr int N = 4; };
+
+template <typename T>
+__device__ __forceinline__ void granule_to_f32(const u32x4_t& g, float* out);
+template <>
+__device__ __forceinline__ void granule_to_f32<float>(const u32x4_t& g, float* out) {
+  out[0] = __uint_as_float(g.x); out[1] = __uint_as_float(g.y);
+  out[2] = __uint_as_float(g.z); out[3] = __uint_as_float(g.w);
+}
+template <>
+__device__ __forceinline__ void granule_to_f32<bf16_t>(const u32x4_t& g, float* out) {
+  out[0] = __uint_as_float(g.x << 16); out[1] = __uint_as_float(g.x & 0xffff0000u);
+  out[2] = __uint_as_float(g.y << 16); out[3] = __uint_as_float(g.y & 0xffff0000u);
+  out[4] = __uint_as_float(g.z << 16); out[5] = __uint_as_float(g.z & 0xffff0000u);
+  out[6] = __uint_as_float(g.w << 16); out[7] = __uint_as_float(g.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
+  unsigned short ua = __builtin_bit_cast(unsigned short, a);
+  unsigned short ub = __builtin_bit_cast(unsigned short, b);
+  return (unsigned)ua | ((unsigned)ub << 16);
+}
+
+template <typename T>
+__device__ __forceinline__ u32x4_t f32_to_granule(const float* in);
+template <>
+__device__ __forceinline__ u32x4_t f32_to_granule<float>(const float* in) {
+  u32x4_t g;
+  g.x = __float_as_uint(in[0]); g.y = __float_as_uint(in[1]);
+  g.z = __float_as_uint(in[2]); g.w = __float_as_uint(in[3]);
+  return g;
+}
+template <>
+__device__ __forceinline__ u32x4_t f32_to_granule<bf16_t>(const float* in) {
+  u32x4_t g;
+  g.x = pack_bf16x2(in[0], in[1]); g.y = pack_bf16x2(in[2], in[3]);
+  g.z = pack_bf16x2(in[4], in[5]); g.w = pack_bf16x2(in[6], in[7]);
+  return g;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) -----------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

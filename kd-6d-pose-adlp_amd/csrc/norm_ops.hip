@@ -1,0 +1,882 @@
+// Normalisation / pooling / resampling kernels of the KD step (NHWC, HBM-bound).
+//
+// Reference ops replaced:
+//   BatchNorm2d (train mode) + LeakyReLU(0.1) of ConvBlock, backbone/common.py:316-324
+//   GroupNorm(32) + ReLU of the PoseHead towers, models/model.py:395-417,438-451
+//   MaxPool2d(2,2), backbone/darknet.py:94-97
+//   F.interpolate(nearest, x2) + add of the FPN top-down path, models/model.py:75-78
+//   F.relu between P6 and P7, models/model.py:101
+// All reductions accumulate in fp32; every kernel reads/writes 16-B granules.
+#include "kd6d_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------
+// Per-channel reductions over rows.  Thread t owns channel granule t % (C/EG);
+// requires (C/EG) | 256.  F(acc, granule index, values...) accumulates NACC sums.
+// ---------------------------------------------------------------------------
+template <int NACC, int EG>
+__device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int C, int cg,
+                                                    float* const* out) {
+  extern __shared__ float red[];  // NACC * C floats
+  for (int i = threadIdx.x; i < NACC * C; i += kThreads) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int e = 0; e < EG; ++e) atomicAdd(&red[a * C + cg * EG + e], acc[a][e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
+    const int a = i / C, c = i - a * C;
+    if (out[a]) atomicAdd(out[a] + c, red[i]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void colstats_kernel(const T* __restrict__ x, long long ngran,
+                                                            int C, float* sum, float* sumsq) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float acc[2][EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    float v[EG];
+    granule_to_f32<T>(xg[g], v);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+  }
+  float* outs[2] = {sum, sumsq};
+  block_channel_flush<2, EG>(acc, C, cg, outs);
+}
+
+// y = act(gamma * (x - mean) * invstd + beta), mean/var from the batch sums.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
+    const T* __restrict__ x, T* __restrict__ y, long long ngran, int C, float inv_rows,
+    const float* __restrict__ sum, const float* __restrict__ sumsq, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float unbias,
+    float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float sc[EG], sh[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    const float m = sum[c] * inv_rows;
+    float var = sumsq[c] * inv_rows - m * m;
+    var = fmaxf(var, 0.f);
+    const float is = rsqrtf(var + eps);
+    sc[e] = gamma[c] * is;
+    sh[e] = beta[c] - m * sc[e];
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      const float m = sum[c] * inv_rows;
+      float var = fmaxf(sumsq[c] * inv_rows - m * m, 0.f);
+      if (save_mean) save_mean[c] = m;
+      if (save_invstd) save_invstd[c] = rsqrtf(var + eps);
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
+    }
+  }
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    float v[EG];
+    granule_to_f32<T>(xg[g], v);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      float t = v[e] * sc[e] + sh[e];
+      if (act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+      else if (act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+      v[e] = t;
+    }
+    yg[g] = f32_to_granule<T>(v);
+  }
+}
+
+// reduce pass of BN backward: sum(dy), sum(dy * xhat) per channel, dy = dz * act'(bn(x))
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dz, long long ngran, int C,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy,
+    float* sum_dy_xhat) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float m[EG], is[EG], ga[EG], be[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+  }
+  float acc[2][EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    float xv[EG], dv[EG];
+    granule_to_f32<T>(xg[g], xv);
+    granule_to_f32<T>(dg[g], dv);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const float xh = (xv[e] - m[e]) * is[e];
+      const float pre = xh * ga[e] + be[e];
+      float d = dv[e];
+      if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+      else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+      acc[0][e] += d;
+      acc[1][e] += d * xh;
+    }
+  }
+  float* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG>(acc, C, cg, outs);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int C,
+    float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* dgamma,
+    float* dbeta) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float m[EG], is[EG], ga[EG], be[EG], k1[EG], k2[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+    k1[e] = sum_dy[c] * inv_rows;
+    k2[e] = sum_dy_xhat[c] * inv_rows;
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      if (dgamma) dgamma[c] += sum_dy_xhat[c];
+      if (dbeta) dbeta[c] += sum_dy[c];
+    }
+  }
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    float xv[EG], dv[EG];
+    granule_to_f32<T>(xg[g], xv);
+    granule_to_f32<T>(dg[g], dv);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const float xh = (xv[e] - m[e]) * is[e];
+      const float pre = xh * ga[e] + be[e];
+      float d = dv[e];
+      if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+      else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+      dv[e] = ga[e] * is[e] * (d - k1[e] - xh * k2[e]);
+    }
+    og[g] = f32_to_granule<T>(dv);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm(G) + ReLU over multi-level NHWC tensors.  One workgroup per
+// (level, sample): rows = H*W pixels, C channels, G groups of C/G channels.
+// ---------------------------------------------------------------------------
+struct GnGeom {
+  int nseg, batch, C, G;
+  int row0[KD6D_MAX_SEG];
+  int hw[KD6D_MAX_SEG];
+};
+
+// stats[(seg*batch + b)*G + g] = {mean, rstd}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict__ x, GnGeom gm,
+                                                            float eps, float* __restrict__ stats) {
+  constexpr int EG = Granule<T>::N;
+  __shared__ float s_sum[64], s_sq[64];
+  const int seg = blockIdx.x / gm.batch, b = blockIdx.x % gm.batch;
+  int row0 = 0, hw = 0;
+#pragma unroll
+  for (int s = 0; s < KD6D_MAX_SEG; ++s)
+    if (s == seg) { row0 = gm.row0[s]; hw = gm.hw[s]; }
+  const int C = gm.C, G = gm.G, cpg = C / G;
+  if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
+  __syncthreads();
+  const int cgs = C / EG;
+  const long long ngran = (long long)hw * cgs;
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x + (size_t)(row0 + b * hw) * C);
+  const int cg = threadIdx.x % cgs;  // (C/EG) | 256
+  // a granule may straddle groups when cpg < EG (C=128,G=32,bf16: 2 groups per granule)
+  float a1[EG], a2[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  for (long long g = threadIdx.x; g < ngran; g += kThreads) {
+    float v[EG];
+    granule_to_f32<T>(xg[g], v);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) { a1[e] += v[e]; a2[e] += v[e] * v[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int grp = (cg * EG + e) / cpg;
+    atomicAdd(&s_sum[grp], a1[e]);
+    atomicAdd(&s_sq[grp], a2[e]);
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const float n = (float)hw * (float)cpg;
+    const float m = s_sum[threadIdx.x] / n;
+    const float var = fmaxf(s_sq[threadIdx.x] / n - m * m, 0.f);
+    float* o = stats + ((size_t)blockIdx.x * G + threadIdx.x) * 2;
+    o[0] = m;
+    o[1] = rsqrtf(var + eps);
+  }
+}
+
+__device__ __forceinline__ void gn_locate(const GnGeom& gm, long long row, int& seg, int& b) {
+  seg = 0; b = 0;
+  int r0 = 0, hw = 1;
+#pragma unroll
+  for (int s = 0; s < KD6D_MAX_SEG; ++s)
+    if (s < gm.nseg && row >= gm.row0[s]) { seg = s; r0 = gm.row0[s]; hw = gm.hw[s]; }
+  b = (int)((row - r0) / hw);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
+    const T* __restrict__ x, T* __restrict__ y, GnGeom gm, long long ngran,
+    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta) {
+  constexpr int EG = Granule<T>::N;
+  const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float ga[EG], be[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    const long long row = g / cgs;
+    int seg, b;
+    gn_locate(gm, row, seg, b);
+    const float* st = stats + ((size_t)(seg * gm.batch + b) * G) * 2;
+    float v[EG];
+    granule_to_f32<T>(xg[g], v);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int grp = (cg * EG + e) / cpg;
+      const float t = (v[e] - st[grp * 2]) * st[grp * 2 + 1] * ga[e] + be[e];
+      v[e] = fmaxf(t, 0.f);
+    }
+    yg[g] = f32_to_granule<T>(v);
+  }
+}
+
+// backward reduce: one workgroup per (level, sample):
+//   gsum[(seg,b,g)] = {sum(dy*gamma), sum(dy*gamma*xhat)}; dgamma/dbeta via atomics.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dz, GnGeom gm, const float* __restrict__ stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gsum,
+    float* dgamma, float* dbeta) {
+  constexpr int EG = Granule<T>::N;
+  __shared__ float s_a[64], s_b[64];
+  extern __shared__ float red[];  // 2*C
+  const int seg = blockIdx.x / gm.batch, b = blockIdx.x % gm.batch;
+  int row0 = 0, hw = 0;
+#pragma unroll
+  for (int s = 0; s < KD6D_MAX_SEG; ++s)
+    if (s == seg) { row0 = gm.row0[s]; hw = gm.hw[s]; }
+  const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
+  if (threadIdx.x < 64) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) red[i] = 0.f;
+  __syncthreads();
+  const int cg = threadIdx.x % cgs;
+  const float* st = stats + ((size_t)blockIdx.x * G) * 2;
+  float ga[EG], be[EG], mu[EG], rs[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    ga[e] = gamma[c]; be[e] = beta[c];
+    mu[e] = st[(c / cpg) * 2]; rs[e] = st[(c / cpg) * 2 + 1];
+  }
+  float a_dy[EG], a_dyx[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { a_dy[e] = 0.f; a_dyx[e] = 0.f; }
+  const size_t base = (size_t)(row0 + b * hw) * C;
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x + base);
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz + base);
+  const long long ngran = (long long)hw * cgs;
+  for (long long g = threadIdx.x; g < ngran; g += kThreads) {
+    float xv[EG], dv[EG];
+    granule_to_f32<T>(xg[g], xv);
+    granule_to_f32<T>(dg[g], dv);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      const float pre = xh * ga[e] + be[e];
+      const float d = pre > 0.f ? dv[e] : 0.f;
+      a_dy[e] += d;
+      a_dyx[e] += d * xh;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    atomicAdd(&red[c], a_dy[e]);
+    atomicAdd(&red[C + c], a_dyx[e]);
+    atomicAdd(&s_a[c / cpg], a_dy[e] * ga[e]);
+    atomicAdd(&s_b[c / cpg], a_dyx[e] * ga[e]);
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float* o = gsum + ((size_t)blockIdx.x * G + threadIdx.x) * 2;
+    o[0] = s_a[threadIdx.x];
+    o[1] = s_b[threadIdx.x];
+  }
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    if (dbeta) atomicAdd(dbeta + c, red[c]);
+    if (dgamma) atomicAdd(dgamma + c, red[C + c]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm,
+    long long ngran, const float* __restrict__ stats, const float* __restrict__ gsum,
+    const float* __restrict__ gamma, const float* __restrict__ beta) {
+  constexpr int EG = Granule<T>::N;
+  const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float ga[EG], be[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    const long long row = g / cgs;
+    int seg, b;
+    gn_locate(gm, row, seg, b);
+    int hw = 1;
+#pragma unroll
+    for (int s = 0; s < KD6D_MAX_SEG; ++s)
+      if (s == seg) hw = gm.hw[s];
+    const float inv_n = 1.f / ((float)hw * (float)cpg);
+    const size_t sb = (size_t)(seg * gm.batch + b) * G;
+    float xv[EG], dv[EG];
+    granule_to_f32<T>(xg[g], xv);
+    granule_to_f32<T>(dg[g], dv);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int grp = (cg * EG + e) / cpg;
+      const float mu = stats[(sb + grp) * 2], rs = stats[(sb + grp) * 2 + 1];
+      const float xh = (xv[e] - mu) * rs;
+      const float pre = xh * ga[e] + be[e];
+      const float d = pre > 0.f ? dv[e] * ga[e] : 0.f;
+      dv[e] = rs * (d - gsum[(sb + grp) * 2] * inv_n - xh * gsum[(sb + grp) * 2 + 1] * inv_n);
+    }
+    og[g] = f32_to_granule<T>(dv);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MaxPool 2x2/2, nearest x2 upsample + add, 2x2 sum-pool (its adjoint), ReLU.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool2_fwd_kernel(const T* __restrict__ x,
+                                                                T* __restrict__ y, int B, int H,
+                                                                int W, int C) {
+  constexpr int EG = Granule<T>::N;
+  const int Ho = H / 2, Wo = W / 2, cgs = C / EG;
+  const long long total = (long long)B * Ho * Wo * cgs;
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < total;
+       g += (long long)gridDim.x * kThreads) {
+    const int cg = (int)(g % cgs);
+    long long r = g / cgs;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float best[EG];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+      float v[EG];
+      granule_to_f32<T>(xg[((long long)(b * H + iy) * W + ix) * cgs + cg], v);
+#pragma unroll
+      for (int e = 0; e < EG; ++e) best[e] = (k == 0 || v[e] > best[e]) ? v[e] : best[e];
+    }
+    yg[g] = f32_to_granule<T>(best);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool2_bwd_kernel(const T* __restrict__ x,
+                                                                const T* __restrict__ dy,
+                                                                T* __restrict__ dx, int B, int H,
+                                                                int W, int C, int accumulate) {
+  constexpr int EG = Granule<T>::N;
+  const int Ho = H / 2, Wo = W / 2, cgs = C / EG;
+  const long long total = (long long)B * Ho * Wo * cgs;
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dy);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < total;
+       g += (long long)gridDim.x * kThreads) {
+    const int cg = (int)(g % cgs);
+    long long r = g / cgs;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float v[4][EG], d[EG], best[EG];
+    int arg[EG];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+      granule_to_f32<T>(xg[((long long)(b * H + iy) * W + ix) * cgs + cg], v[k]);
+#pragma unroll
+      for (int e = 0; e < EG; ++e)
+        if (k == 0 || v[k][e] > best[e]) { best[e] = v[k][e]; arg[e] = k; }
+    }
+    granule_to_f32<T>(dg[g], d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+      const long long o = ((long long)(b * H + iy) * W + ix) * cgs + cg;
+      float out[EG];
+      if (accumulate) granule_to_f32<T>(og[o], out);
+#pragma unroll
+      for (int e = 0; e < EG; ++e) {
+        const float t = arg[e] == k ? d[e] : 0.f;
+        out[e] = accumulate ? out[e] + t : t;
+      }
+      og[o] = f32_to_granule<T>(out);
+    }
+  }
+}
+
+// out[b,y,x,:] = fine[b,y,x,:] + coarse[b,y/2,x/2,:]   (fine grid H x W, coarse H/2 x W/2)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample2_add_kernel(const T* __restrict__ fine,
+                                                                 const T* __restrict__ coarse,
+                                                                 T* __restrict__ out, int B, int H,
+                                                                 int W, int C) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG, Hc = H / 2, Wc = W / 2;
+  const long long total = (long long)B * H * W * cgs;
+  const u32x4_t* fg = reinterpret_cast<const u32x4_t*>(fine);
+  const u32x4_t* cgp = reinterpret_cast<const u32x4_t*>(coarse);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(out);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < total;
+       g += (long long)gridDim.x * kThreads) {
+    const int cg = (int)(g % cgs);
+    long long r = g / cgs;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float a[EG], c[EG];
+    granule_to_f32<T>(fg[g], a);
+    granule_to_f32<T>(cgp[((long long)(b * Hc + (y >> 1)) * Wc + (x >> 1)) * cgs + cg], c);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) a[e] += c[e];
+    og[g] = f32_to_granule<T>(a);
+  }
+}
+
+// dcoarse[b,y,x,:] (+)= sum of the 2x2 fine block of dfine
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sumpool2_kernel(const T* __restrict__ dfine,
+                                                            T* __restrict__ dcoarse, int B, int H,
+                                                            int W, int C, int accumulate) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG, Hc = H / 2, Wc = W / 2;
+  const long long total = (long long)B * Hc * Wc * cgs;
+  const u32x4_t* fg = reinterpret_cast<const u32x4_t*>(dfine);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dcoarse);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < total;
+       g += (long long)gridDim.x * kThreads) {
+    const int cg = (int)(g % cgs);
+    long long r = g / cgs;
+    const int x = (int)(r % Wc); r /= Wc;
+    const int y = (int)(r % Hc);
+    const int b = (int)(r / Hc);
+    float s[EG];
+    if (accumulate) granule_to_f32<T>(og[g], s);
+    else {
+#pragma unroll
+      for (int e = 0; e < EG; ++e) s[e] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v[EG];
+      granule_to_f32<T>(fg[((long long)(b * H + 2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * cgs + cg], v);
+#pragma unroll
+      for (int e = 0; e < EG; ++e) s[e] += v[e];
+    }
+    og[g] = f32_to_granule<T>(s);
+  }
+}
+
+// mode 0: y = relu(x);  mode 1: y = (x > 0) ? dy : 0   (ReLU backward with x = forward input)
+// mode 2: y = x + dy (elementwise add)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void eltwise_kernel(const T* __restrict__ x,
+                                                           const T* __restrict__ dy,
+                                                           T* __restrict__ y, long long ngran,
+                                                           int mode) {
+  constexpr int EG = Granule<T>::N;
+  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dy);
+  u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
+       g += (long long)gridDim.x * kThreads) {
+    float a[EG], d[EG];
+    granule_to_f32<T>(xg[g], a);
+    if (mode != 0) granule_to_f32<T>(dg[g], d);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      if (mode == 0) a[e] = fmaxf(a[e], 0.f);
+      else if (mode == 1) a[e] = a[e] > 0.f ? d[e] : 0.f;
+      else a[e] = a[e] + d[e];
+    }
+    yg[g] = f32_to_granule<T>(a);
+  }
+}
+
+// NCHW fp32 image (B,Cimg,H,W) -> NHWC T (B,H,W,Cpad), zero padded channels
+template <typename T>
+__global__ __launch_bounds__(kThreads) void image_to_nhwc_kernel(const float* __restrict__ img,
+                                                                 T* __restrict__ out, int B,
+                                                                 int Cimg, int H, int W, int Cpad) {
+  const long long total = (long long)B * H * W;
+  for (long long p = (long long)blockIdx.x * kThreads + threadIdx.x; p < total;
+       p += (long long)gridDim.x * kThreads) {
+    const long long hw = (long long)H * W;
+    const int b = (int)(p / hw);
+    const long long r = p - (long long)b * hw;
+    for (int c = 0; c < Cpad; ++c) {
+      const float v = c < Cimg ? img[((long long)b * Cimg + c) * hw + r] : 0.f;
+      out[p * Cpad + c] = from_f32<T>(v);
+    }
+  }
+}
+
+int grid_for(long long work_items) {
+  long long b = (work_items + kThreads - 1) / kThreads;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int check_channels(int dtype, int C, const char* who) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "%s: bad dtype %d", who, dtype);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(C > 0 && C % eg == 0, "%s: C=%d must be a multiple of %d", who, C, eg);
+  const int cgs = C / eg;
+  KD6D_CHECK_ARG(cgs <= 256 && 256 % cgs == 0, "%s: C=%d: C/%d must divide 256", who, C, eg);
+  return KD6D_OK;
+}
+
+bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom* gm) {
+  if (nseg < 1 || nseg > KD6D_MAX_SEG || batch < 1 || G < 1 || G > 64 || C % G) return false;
+  gm->nseg = nseg; gm->batch = batch; gm->C = C; gm->G = G;
+  int row = 0;
+  for (int s = 0; s < KD6D_MAX_SEG; ++s) {
+    gm->row0[s] = row;
+    gm->hw[s] = s < nseg ? level_hw[s] : 0;
+    if (s < nseg) {
+      if (level_hw[s] <= 0) return false;
+      row += batch * level_hw[s];
+    }
+  }
+  return true;
+}
+
+long long gn_rows(const GnGeom& gm) {
+  long long r = 0;
+  for (int s = 0; s < gm.nseg; ++s) r += (long long)gm.batch * gm.hw[s];
+  return r;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, expr_bf16, expr_f32) \
+  do { if ((dtype) == KD6D_BF16) { expr_bf16; } else { expr_f32; } } while (0)
+
+extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum,
+                             float* sumsq, void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_colstats");
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && rows > 0, "kd6d_colstats: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = rows * (C / eg);
+  long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((int)nb), dim3(kThreads), lds, st,
+                                (const bf16_t*)x, ngran, C, sum, sumsq),
+             hipLaunchKernelGGL(colstats_kernel<float>, dim3((int)nb), dim3(kThreads), lds, st,
+                                (const float*)x, ngran, C, sum, sumsq));
+  KD6D_CHECK_LAUNCH("kd6d_colstats");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_bn_train_fwd(int dtype, const void* x, void* y, int64_t rows, int C,
+                                 const float* sum, const float* sumsq, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* save_mean, float* save_invstd, int act,
+                                 void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_bn_train_fwd");
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && y && sum && sumsq && gamma && beta && rows > 0, "kd6d_bn_train_fwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = rows * (C / eg);
+  const float inv_rows = 1.f / (float)rows;
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  const int nb = grid_for((ngran + 3) / 4);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)x, (bf16_t*)y, ngran, C, inv_rows, sum, sumsq, gamma,
+                                beta, eps, momentum, unbias, running_mean, running_var, save_mean,
+                                save_invstd, act),
+             hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)x, (float*)y, ngran, C, inv_rows, sum, sumsq, gamma,
+                                beta, eps, momentum, unbias, running_mean, running_var, save_mean,
+                                save_invstd, act));
+  KD6D_CHECK_LAUNCH("kd6d_bn_train_fwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_bn_train_bwd_reduce(int dtype, const void* x, const void* dz, int64_t rows, int C,
+                                        const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, int act, float* sum_dy,
+                                        float* sum_dy_xhat, void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_reduce");
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && dz && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
+                 "kd6d_bn_train_bwd_reduce: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = rows * (C / eg);
+  long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)nb), dim3(kThreads), lds, st,
+                                (const bf16_t*)x, (const bf16_t*)dz, ngran, C, mean, invstd, gamma,
+                                beta, act, sum_dy, sum_dy_xhat),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)nb), dim3(kThreads), lds, st,
+                                (const float*)x, (const float*)dz, ngran, C, mean, invstd, gamma,
+                                beta, act, sum_dy, sum_dy_xhat));
+  KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_reduce");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_bn_train_bwd_apply(int dtype, const void* x, const void* dz, void* dx,
+                                       int64_t rows, int C, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, int act,
+                                       const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
+                                       float* dbeta, void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_apply");
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && dz && dx && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
+                 "kd6d_bn_train_bwd_apply: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = rows * (C / eg);
+  const int nb = grid_for((ngran + 3) / 4);
+  const float inv_rows = 1.f / (float)rows;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)x, (const bf16_t*)dz, (bf16_t*)dx, ngran, C, inv_rows,
+                                mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)x, (const float*)dz, (float*)dx, ngran, C, inv_rows,
+                                mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta));
+  KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_apply");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_gn_relu_fwd(int dtype, const void* x, void* y, const int32_t* level_hw_host,
+                                int nseg, int batch, int C, int groups, const float* gamma,
+                                const float* beta, float eps, float* stats, void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_gn_relu_fwd");
+  if (rc) return rc;
+  GnGeom gm;
+  KD6D_CHECK_ARG(level_hw_host && fill_gn(level_hw_host, nseg, batch, C, groups, &gm),
+                 "kd6d_gn_relu_fwd: bad level table / groups");
+  KD6D_CHECK_ARG(x && y && gamma && beta && stats, "kd6d_gn_relu_fwd: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = gn_rows(gm) * (C / eg);
+  const int nb = grid_for((ngran + 3) / 4);
+  DISPATCH_T(dtype,
+             { hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nseg * batch), dim3(kThreads), 0, st,
+                                  (const bf16_t*)x, gm, eps, stats);
+               hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                  (const bf16_t*)x, (bf16_t*)y, gm, ngran, stats, gamma, beta); },
+             { hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nseg * batch), dim3(kThreads), 0, st,
+                                  (const float*)x, gm, eps, stats);
+               hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                  (const float*)x, (float*)y, gm, ngran, stats, gamma, beta); });
+  KD6D_CHECK_LAUNCH("kd6d_gn_relu_fwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_gn_relu_bwd(int dtype, const void* x, const void* dz, void* dx,
+                                const int32_t* level_hw_host, int nseg, int batch, int C, int groups,
+                                const float* gamma, const float* beta, const float* stats,
+                                float* gsum_ws, float* dgamma, float* dbeta, void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_gn_relu_bwd");
+  if (rc) return rc;
+  GnGeom gm;
+  KD6D_CHECK_ARG(level_hw_host && fill_gn(level_hw_host, nseg, batch, C, groups, &gm),
+                 "kd6d_gn_relu_bwd: bad level table / groups");
+  KD6D_CHECK_ARG(x && dz && dx && gamma && beta && stats && gsum_ws, "kd6d_gn_relu_bwd: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = gn_rows(gm) * (C / eg);
+  const int nb = grid_for((ngran + 3) / 4);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  DISPATCH_T(dtype,
+             { hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<bf16_t>, dim3(nseg * batch), dim3(kThreads),
+                                  lds, st, (const bf16_t*)x, (const bf16_t*)dz, gm, stats, gamma, beta,
+                                  gsum_ws, dgamma, dbeta);
+               hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                  (const bf16_t*)x, (const bf16_t*)dz, (bf16_t*)dx, gm, ngran, stats,
+                                  gsum_ws, gamma, beta); },
+             { hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<float>, dim3(nseg * batch), dim3(kThreads),
+                                  lds, st, (const float*)x, (const float*)dz, gm, stats, gamma, beta,
+                                  gsum_ws, dgamma, dbeta);
+               hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                  (const float*)x, (const float*)dz, (float*)dx, gm, ngran, stats,
+                                  gsum_ws, gamma, beta); });
+  KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_maxpool2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C,
+                                 void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_maxpool2_fwd: bad dtype");
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C % eg == 0, "kd6d_maxpool2_fwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / eg);
+  const int nb = grid_for(total);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)x, (bf16_t*)y, B, H, W, C),
+             hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)x, (float*)y, B, H, W, C));
+  KD6D_CHECK_LAUNCH("kd6d_maxpool2_fwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H,
+                                 int W, int C, int accumulate, void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_maxpool2_bwd: bad dtype");
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C % eg == 0 && H % 2 == 0 && W % 2 == 0,
+                 "kd6d_maxpool2_bwd: bad arguments (H, W must be even)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / eg);
+  const int nb = grid_for(total);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, accumulate),
+             hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)x, (const float*)dy, (float*)dx, B, H, W, C, accumulate));
+  KD6D_CHECK_LAUNCH("kd6d_maxpool2_bwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_upsample2_add(int dtype, const void* fine, const void* coarse, void* out, int B,
+                                  int H, int W, int C, void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_upsample2_add: bad dtype");
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(fine && coarse && out && B > 0 && H % 2 == 0 && W % 2 == 0 && C % eg == 0,
+                 "kd6d_upsample2_add: bad arguments (H, W must be even)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)B * H * W * (C / eg);
+  const int nb = grid_for(total);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(upsample2_add_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)fine, (const bf16_t*)coarse, (bf16_t*)out, B, H, W, C),
+             hipLaunchKernelGGL(upsample2_add_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)fine, (const float*)coarse, (float*)out, B, H, W, C));
+  KD6D_CHECK_LAUNCH("kd6d_upsample2_add");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_sumpool2(int dtype, const void* dfine, void* dcoarse, int B, int H, int W, int C,
+                             int accumulate, void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_sumpool2: bad dtype");
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(dfine && dcoarse && B > 0 && H % 2 == 0 && W % 2 == 0 && C % eg == 0,
+                 "kd6d_sumpool2: bad arguments (H, W must be even)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / eg);
+  const int nb = grid_for(total);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(sumpool2_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)dfine, (bf16_t*)dcoarse, B, H, W, C, accumulate),
+             hipLaunchKernelGGL(sumpool2_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)dfine, (float*)dcoarse, B, H, W, C, accumulate));
+  KD6D_CHECK_LAUNCH("kd6d_sumpool2");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_eltwise(int dtype, int mode, const void* x, const void* dy, void* y,
+                            int64_t n_elems, void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_eltwise: bad dtype");
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(x && y && n_elems > 0 && n_elems % eg == 0 && mode >= 0 && mode <= 2 &&
+                     (mode == 0 || dy),
+                 "kd6d_eltwise: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long ngran = n_elems / eg;
+  const int nb = grid_for(ngran);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(eltwise_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
+                                (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)y, ngran, mode),
+             hipLaunchKernelGGL(eltwise_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+                                (const float*)x, (const float*)dy, (float*)y, ngran, mode));
+  KD6D_CHECK_LAUNCH("kd6d_eltwise");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_image_to_nhwc(int dtype, const float* img_nchw, void* out, int B, int Cimg, int H,
+                                  int W, int Cpad, void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_image_to_nhwc: bad dtype");
+  KD6D_CHECK_ARG(img_nchw && out && B > 0 && Cimg > 0 && Cpad >= Cimg && H > 0 && W > 0,
+                 "kd6d_image_to_nhwc: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nb = grid_for((long long)B * H * W);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(image_to_nhwc_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st, img_nchw,
+                                (bf16_t*)out, B, Cimg, H, W, Cpad),
+             hipLaunchKernelGGL(image_to_nhwc_kernel<float>, dim3(nb), dim3(kThreads), 0, st, img_nchw,
+                                (float*)out, B, Cimg, H, W, Cpad));
+  KD6D_CHECK_LAUNCH("kd6d_image_to_nhwc");
+  return KD6D_OK;
+}

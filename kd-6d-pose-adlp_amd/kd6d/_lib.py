@@ -1,0 +1,94 @@
+"""ctypes binding of libkd6d.so (the C ABI declared in include/kd6d.h).
+
+The library is the product; there is no CPU fallback.  Importing this module without a
+built libkd6d.so raises immediately (build with `python kd-6d-pose-adlp_amd/build.py`
+or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libkd6d.so")
+
+KD6D_BF16 = 0
+KD6D_F32 = 1
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+MAX_SEG = 5
+ABI_VERSION = 1
+
+
+class Seg(ctypes.Structure):
+    _fields_ = [("in_h", ctypes.c_int32), ("in_w", ctypes.c_int32),
+                ("out_h", ctypes.c_int32), ("out_w", ctypes.c_int32),
+                ("in_row0", ctypes.c_int32), ("out_row0", ctypes.c_int32)]
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [("nseg", ctypes.c_int32), ("batch", ctypes.c_int32),
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
+                ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
+                ("pad", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("seg", Seg * MAX_SEG)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_I64 = ctypes.c_int64
+_F = ctypes.c_float
+_G = ctypes.POINTER(ConvGeom)
+
+# name -> argtypes (every function returns int unless listed in _RESTYPE)
+SIGNATURES = {
+    "kd6d_abi_version": [],
+    "kd6d_device_cu_count": [],
+    "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
+    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P],
+    "kd6d_pack_dgrad_weights": [_I, _P, _P, _P, _I, _I, _P],
+    "kd6d_colstats": [_I, _P, _I64, _I, _P, _P, _P],
+    "kd6d_bn_train_fwd": [_I, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
+    "kd6d_bn_train_bwd_reduce": [_I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "kd6d_bn_train_bwd_apply": [_I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "kd6d_gn_relu_fwd": [_I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _P],
+    "kd6d_gn_relu_bwd": [_I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _P,
+                         _P, _P, _P, _P],
+    "kd6d_maxpool2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "kd6d_maxpool2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "kd6d_upsample2_add": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kd6d_sumpool2": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "kd6d_eltwise": [_I, _I, _P, _P, _P, _I64, _P],
+    "kd6d_image_to_nhwc": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "kd6d_sinkhorn_div_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P],
+    "kd6d_sinkhorn_max_points": [],
+}
+_RESTYPE = {"kd6d_last_error": ctypes.c_char_p}
+
+
+class Kd6dError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libkd6d.so not found at %s -- the HIP extension is the product path and has no "
+            "fallback; build it with `python kd-6d-pose-adlp_amd/build.py`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.kd6d_last_error.restype = ctypes.c_char_p
+    lib.kd6d_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if lib.kd6d_abi_version() != ABI_VERSION:
+        raise ImportError("libkd6d.so ABI version %d != expected %d" % (lib.kd6d_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.kd6d_last_error()
+        raise Kd6dError("%s failed (rc=%d): %s" % (what or "kd6d call", rc, msg.decode() if msg else "?"))

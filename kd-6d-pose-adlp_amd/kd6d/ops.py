@@ -1,0 +1,221 @@
+"""Thin Python wrappers over the C ABI: tensors in, tensors out, no arithmetic here.
+
+All activations are "packed NHWC": a 2-D tensor (rows, C) whose rows are the pixels of
+one or several pyramid levels laid out level-major, then image, then row-major (y, x).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvGeom, check, lib  # noqa: F401
+
+
+def dt_code(dtype):
+    if dtype == torch.bfloat16:
+        return _lib.KD6D_BF16
+    if dtype == torch.float32:
+        return _lib.KD6D_F32
+    raise TypeError("kd6d supports bfloat16 and float32 activations, got %s" % dtype)
+
+
+def granule(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "kd6d ops need contiguous device tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Geom:
+    """Forward-sense geometry of one conv layer over 1..5 pyramid levels."""
+
+    def __init__(self, batch, cin, cout, ksize, stride, pad, levels):
+        assert 1 <= len(levels) <= _lib.MAX_SEG
+        self.batch, self.cin, self.cout = batch, cin, cout
+        self.ksize, self.stride, self.pad = ksize, stride, pad
+        self.levels_in = [tuple(l) for l in levels]
+        self.levels_out = [((h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1)
+                           for (h, w) in self.levels_in]
+        g = ConvGeom()
+        g.nseg, g.batch, g.cin, g.cout = len(levels), batch, cin, cout
+        g.ksize, g.stride, g.pad = ksize, stride, pad
+        rin = rout = 0
+        for s, ((h, w), (ho, wo)) in enumerate(zip(self.levels_in, self.levels_out)):
+            g.seg[s].in_h, g.seg[s].in_w, g.seg[s].out_h, g.seg[s].out_w = h, w, ho, wo
+            g.seg[s].in_row0, g.seg[s].out_row0 = rin, rout
+            rin += batch * h * w
+            rout += batch * ho * wo
+        self.rows_in, self.rows_out = rin, rout
+        self.c = g
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE, residual=None,
+               seg_scale=None, out_f32=False):
+    assert x.shape == (geom.rows_in, geom.cin), (x.shape, geom.rows_in, geom.cin)
+    assert w.dtype == x.dtype and w.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
+    odt = torch.float32 if out_f32 else x.dtype
+    if out is None:
+        out = torch.empty((geom.rows_out, geom.cout), dtype=odt, device=x.device)
+    assert out.shape == (geom.rows_out, geom.cout) and out.dtype == odt
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == odt
+    for v in (ch_scale, ch_shift):
+        assert v is None or (v.dtype == torch.float32 and v.numel() >= geom.cout)
+    assert seg_scale is None or (seg_scale.dtype == torch.float32 and seg_scale.numel() >= len(geom.levels_in))
+    check(lib.kd6d_conv2d_fwd(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(out), _ptr(ch_scale),
+                              _ptr(ch_shift), act, _ptr(residual), _ptr(seg_scale), int(out_f32),
+                              _stream()), "kd6d_conv2d_fwd")
+    return out
+
+
+def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False):
+    assert dy.shape == (geom.rows_out, geom.cout), (dy.shape, geom.rows_out, geom.cout)
+    assert wt.dtype == dy.dtype and wt.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
+    if dx is None:
+        assert not accumulate
+        dx = torch.empty((geom.rows_in, geom.cin), dtype=dy.dtype, device=dy.device)
+    assert dx.shape == (geom.rows_in, geom.cin) and dx.dtype == dy.dtype
+    check(lib.kd6d_conv2d_dgrad(geom.ref, dt_code(dy.dtype), _ptr(dy), _ptr(wt), _ptr(dx),
+                                int(accumulate), _stream()), "kd6d_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(geom, x, dy, dw):
+    assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
+    assert x.dtype == dy.dtype and dw.dtype == torch.float32
+    assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
+    check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _stream()),
+          "kd6d_conv2d_wgrad")
+    return dw
+
+
+def pack_dgrad_weights(w_base, wt_base, desc_dev, n_layers, total_blocks):
+    check(lib.kd6d_pack_dgrad_weights(dt_code(w_base.dtype), _ptr(w_base), _ptr(wt_base), _ptr(desc_dev),
+                                      n_layers, total_blocks, _stream()), "kd6d_pack_dgrad_weights")
+
+
+def colstats(x, sum_, sumsq=None):
+    rows, c = x.shape
+    check(lib.kd6d_colstats(dt_code(x.dtype), _ptr(x), rows, c, _ptr(sum_), _ptr(sumsq), _stream()),
+          "kd6d_colstats")
+
+
+def bn_train_fwd(x, y, sum_, sumsq, gamma, beta, eps, momentum, running_mean, running_var,
+                 save_mean, save_invstd, act):
+    rows, c = x.shape
+    check(lib.kd6d_bn_train_fwd(dt_code(x.dtype), _ptr(x), _ptr(y), rows, c, _ptr(sum_), _ptr(sumsq),
+                                _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
+                                _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), act, _stream()),
+          "kd6d_bn_train_fwd")
+    return y
+
+
+def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta):
+    rows, c = x.shape
+    code = dt_code(x.dtype)
+    check(lib.kd6d_bn_train_bwd_reduce(code, _ptr(x), _ptr(dz), rows, c, _ptr(mean), _ptr(invstd),
+                                       _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
+                                       _ptr(ws_sum_dy_xhat), _stream()), "kd6d_bn_train_bwd_reduce")
+    check(lib.kd6d_bn_train_bwd_apply(code, _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
+                                      _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
+                                      _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), _stream()),
+          "kd6d_bn_train_bwd_apply")
+    return dx
+
+
+def _hw_array(level_hw):
+    arr = (ctypes.c_int32 * len(level_hw))(*[int(v) for v in level_hw])
+    return arr
+
+
+def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats):
+    rows, c = x.shape
+    assert rows == batch * sum(level_hw)
+    assert stats.numel() >= len(level_hw) * batch * groups * 2
+    check(lib.kd6d_gn_relu_fwd(dt_code(x.dtype), _ptr(x), _ptr(y), _hw_array(level_hw), len(level_hw),
+                               batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats), _stream()),
+          "kd6d_gn_relu_fwd")
+    return y
+
+
+def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta):
+    rows, c = x.shape
+    assert rows == batch * sum(level_hw)
+    check(lib.kd6d_gn_relu_bwd(dt_code(x.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
+                               len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), _ptr(stats),
+                               _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), _stream()), "kd6d_gn_relu_bwd")
+    return dx
+
+
+def maxpool2_fwd(x, y, b, h, w):
+    c = x.shape[-1]
+    check(lib.kd6d_maxpool2_fwd(dt_code(x.dtype), _ptr(x), _ptr(y), b, h, w, c, _stream()),
+          "kd6d_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x, dy, dx, b, h, w, accumulate=False):
+    c = x.shape[-1]
+    check(lib.kd6d_maxpool2_bwd(dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dx), b, h, w, c,
+                                int(accumulate), _stream()), "kd6d_maxpool2_bwd")
+    return dx
+
+
+def upsample2_add(fine, coarse, out, b, h, w):
+    c = fine.shape[-1]
+    check(lib.kd6d_upsample2_add(dt_code(fine.dtype), _ptr(fine), _ptr(coarse), _ptr(out), b, h, w, c,
+                                 _stream()), "kd6d_upsample2_add")
+    return out
+
+
+def sumpool2(dfine, dcoarse, b, h, w, accumulate=False):
+    c = dfine.shape[-1]
+    check(lib.kd6d_sumpool2(dt_code(dfine.dtype), _ptr(dfine), _ptr(dcoarse), b, h, w, c,
+                            int(accumulate), _stream()), "kd6d_sumpool2")
+    return dcoarse
+
+
+ELT_RELU, ELT_RELU_BWD, ELT_ADD = 0, 1, 2
+
+
+def eltwise(mode, x, dy, y):
+    check(lib.kd6d_eltwise(dt_code(x.dtype), mode, _ptr(x), _ptr(dy), _ptr(y), x.numel(), _stream()),
+          "kd6d_eltwise")
+    return y
+
+
+def image_to_nhwc(img, dtype, cpad=8, out=None):
+    b, c, h, w = img.shape
+    assert img.dtype == torch.float32
+    if out is None:
+        out = torch.empty((b * h * w, cpad), dtype=dtype, device=img.device)
+    check(lib.kd6d_image_to_nhwc(dt_code(dtype), _ptr(img), _ptr(out), b, c, h, w, cpad, _stream()),
+          "kd6d_image_to_nhwc")
+    return out
+
+
+def sinkhorn_div(xs, alpha, s_off, yt, beta, t_off, n_images, p, blur, scaling, reach):
+    """xs (P,8,2), alpha (P,8), s_off (B+1) int32, yt (M,8,2), beta (M,8), t_off (B+1).
+    Returns loss_img (B), valid_img (B) int32, grad_xs (P,8,2), grad_alpha (P,8)."""
+    dev = xs.device
+    loss = torch.empty(n_images, dtype=torch.float32, device=dev)
+    valid = torch.empty(n_images, dtype=torch.int32, device=dev)
+    gx = torch.zeros_like(xs)
+    ga = torch.zeros_like(alpha)
+    check(lib.kd6d_sinkhorn_div_fwd_bwd(_ptr(xs), _ptr(alpha), _ptr(s_off), _ptr(yt), _ptr(beta),
+                                        _ptr(t_off), n_images, p, blur, scaling,
+                                        reach if reach is not None else -1.0, _ptr(loss), _ptr(valid),
+                                        _ptr(gx), _ptr(ga), _stream()), "kd6d_sinkhorn_div_fwd_bwd")
+    return loss, valid, gx, ga

@@ -1,0 +1,338 @@
+"""Per-kernel parity: every HIP kernel through the C ABI vs. the same op computed on the
+host CPU in fp32/fp64 (torch CPU ops are the oracle here: the reference itself is plain
+torch conv2d / batch_norm / group_norm / max_pool2d / interpolate).
+
+bf16 kernels are checked on bf16-representable inputs against an fp32 CPU result, so the
+only differences are fp32 accumulation order (tolerance 2e-5 * sum|a*b| bound, stated per
+test) and, where the output is stored in bf16, one bf16 rounding (2^-8 relative).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util_pack import pack_levels, round_to, unpack_levels, w_to_dgrad, w_to_krsc
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float32]
+
+
+def _ops():
+    from kd6d import ops
+    return ops
+
+
+def _tol(dtype, stored):
+    # stored=True: result was rounded to `dtype` on the way out
+    if dtype == torch.float32:
+        return dict(rtol=2e-4, atol=2e-4)
+    return dict(rtol=1.2e-2, atol=1.2e-2) if stored else dict(rtol=2e-4, atol=2e-4)
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, k, stride, levels)
+    (2, 8, 16, 3, 1, [(12, 10)]),
+    (2, 16, 8, 1, 1, [(9, 7)]),
+    (2, 32, 64, 3, 2, [(16, 16)]),
+    (1, 64, 128, 3, 1, [(8, 8)]),
+    (2, 128, 256, 1, 1, [(4, 4)]),
+    (3, 24, 40, 3, 1, [(8, 8), (4, 4), (2, 2)]),       # multi-level, odd channel counts
+    (2, 128, 16, 3, 1, [(8, 8), (4, 4), (2, 2), (1, 1)]),
+    (1, 256, 512, 3, 2, [(6, 6)]),
+    (2, 8, 32, 3, 1, [(40, 40)]),                      # exercises the 256-pixel tiles
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_plain(gpu_device, dtype, case):
+    ops = _ops()
+    B, Cin, Cout, k, stride, levels = case
+    g = torch.Generator().manual_seed(B * 1000 + Cin * 7 + Cout)
+    pad = k // 2
+    xs = [round_to(torch.randn(B, Cin, h, w, generator=g), dtype) for (h, w) in levels]
+    w = round_to(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, dtype)
+    geom = ops.Geom(B, Cin, Cout, k, stride, pad, levels)
+    y = ops.conv2d_fwd(geom, pack_levels(xs, dtype).to(gpu_device), w_to_krsc(w, dtype).to(gpu_device),
+                       out_f32=True)
+    torch.cuda.synchronize()
+    got = unpack_levels(y.cpu(), B, geom.levels_out)
+    for x, gl in zip(xs, got):
+        ref = F.conv2d(x, w, stride=stride, padding=pad)
+        torch.testing.assert_close(gl, ref, **_tol(dtype, stored=False))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fwd_epilogue(gpu_device, dtype):
+    ops = _ops()
+    B, Cin, Cout, k, levels = 2, 32, 48, 3, [(8, 8), (4, 4)]
+    g = torch.Generator().manual_seed(7)
+    xs = [round_to(torch.randn(B, Cin, h, w, generator=g), dtype) for (h, w) in levels]
+    res = [round_to(torch.randn(B, Cout, h, w, generator=g), dtype) for (h, w) in levels]
+    w = round_to(torch.randn(Cout, Cin, k, k, generator=g) * 0.05, dtype)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    segs = torch.tensor([1.5, 0.25])
+    geom = ops.Geom(B, Cin, Cout, k, 1, 1, levels)
+    dev = gpu_device
+    for act in (0, 1, 2):
+        y = ops.conv2d_fwd(geom, pack_levels(xs, dtype).to(dev), w_to_krsc(w, dtype).to(dev),
+                           ch_scale=scale.to(dev), ch_shift=shift.to(dev), act=act,
+                           residual=pack_levels(res, dtype).to(dev), seg_scale=segs.to(dev))
+        torch.cuda.synchronize()
+        got = unpack_levels(y.cpu(), B, levels)
+        for li, (x, r, gl) in enumerate(zip(xs, res, got)):
+            ref = F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            ref = ref * segs[li]
+            if act == 1:
+                ref = F.leaky_relu(ref, 0.1)
+            elif act == 2:
+                ref = F.relu(ref)
+            ref = ref + r
+            torch.testing.assert_close(gl, ref, **_tol(dtype, stored=True))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(gpu_device, dtype, case):
+    ops = _ops()
+    B, Cin, Cout, k, stride, levels = case
+    eg = 8 if dtype == torch.bfloat16 else 4
+    if Cout % eg:
+        pytest.skip("dgrad needs cout %% %d == 0" % eg)
+    g = torch.Generator().manual_seed(11)
+    pad = k // 2
+    geom = ops.Geom(B, Cin, Cout, k, stride, pad, levels)
+    w = round_to(torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5, dtype)
+    dys = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
+    dx0 = [round_to(torch.randn(B, Cin, h, w_, generator=g), dtype) for (h, w_) in levels]
+    dev = gpu_device
+    wt = w_to_dgrad(w, dtype).to(dev)
+    dx = ops.conv2d_dgrad(geom, pack_levels(dys, dtype).to(dev), wt)
+    dx_acc = pack_levels(dx0, dtype).to(dev)
+    ops.conv2d_dgrad(geom, pack_levels(dys, dtype).to(dev), wt, dx=dx_acc, accumulate=True)
+    torch.cuda.synchronize()
+    got = unpack_levels(dx.cpu(), B, levels)
+    got_acc = unpack_levels(dx_acc.cpu(), B, levels)
+    for (h, w_), dy, gl, ga, d0 in zip(levels, dys, got, got_acc, dx0):
+        ref = torch.nn.grad.conv2d_input((B, Cin, h, w_), w, dy, stride=stride, padding=pad)
+        torch.testing.assert_close(gl, ref, **_tol(dtype, stored=True))
+        torch.testing.assert_close(ga, ref + d0, **_tol(dtype, stored=True))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(gpu_device, dtype, case):
+    ops = _ops()
+    B, Cin, Cout, k, stride, levels = case
+    eg = 8 if dtype == torch.bfloat16 else 4
+    if Cout % eg:
+        pytest.skip("wgrad needs cout %% %d == 0" % eg)
+    g = torch.Generator().manual_seed(13)
+    pad = k // 2
+    geom = ops.Geom(B, Cin, Cout, k, stride, pad, levels)
+    xs = [round_to(torch.randn(B, Cin, h, w_, generator=g), dtype) for (h, w_) in levels]
+    dys = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
+    dev = gpu_device
+    dw = torch.zeros(Cout, k, k, Cin, dtype=torch.float32, device=dev)
+    ops.conv2d_wgrad(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), dw)
+    torch.cuda.synchronize()
+    ref = torch.zeros(Cout, Cin, k, k)
+    for x, dy in zip(xs, dys):
+        ref += torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=stride, padding=pad)
+    got = dw.cpu().permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4 * max(scale, 1.0))
+
+
+def test_pack_dgrad_weights(gpu_device):
+    ops = _ops()
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    shapes = [(16, 8, 3), (8, 16, 1), (40, 24, 3)]
+    for dtype in DTYPES:
+        ws = [torch.randn(o, k, k, i, generator=g).to(dtype) for (o, i, k) in shapes]
+        flat = torch.cat([w.reshape(-1) for w in ws]).to(dev)
+        out = torch.zeros_like(flat)
+        desc, off, blk = [], 0, 0
+        for (o, i, k) in shapes:
+            n = o * i * k * k
+            desc += [off, off, o, i, k, blk]
+            off += n
+            blk += (n + 2047) // 2048
+        ops.pack_dgrad_weights(flat, out, torch.tensor(desc, dtype=torch.int32, device=dev), len(shapes), blk)
+        torch.cuda.synchronize()
+        off = 0
+        for w, (o, i, k) in zip(ws, shapes):
+            n = o * i * k * k
+            got = out[off:off + n].cpu().reshape(i, k, k, o)
+            assert torch.equal(got, w.permute(3, 1, 2, 0).contiguous())
+            off += n
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64)])
+def test_batchnorm_train_fwd_bwd(gpu_device, dtype, C, rows):
+    ops = _ops()
+    dev = gpu_device
+    g = torch.Generator().manual_seed(C + rows)
+    x = round_to(torch.randn(rows, C, generator=g) * 2 + 0.5, dtype)
+    dz = round_to(torch.randn(rows, C, generator=g), dtype)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.zeros(C), torch.ones(C)
+    # CPU oracle (double)
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    yr = F.leaky_relu(F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5), 0.1)
+    yr.backward(dz.double())
+    xd, dzd = x.to(dtype).to(dev), dz.to(dtype).to(dev)
+    s1 = torch.zeros(C, device=dev); s2 = torch.zeros(C, device=dev)
+    ops.colstats(xd, s1, s2)
+    y = torch.empty_like(xd)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
+    ops.bn_train_fwd(xd, y, s1, s2, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm_d, rv_d, mean, invstd, 1)
+    dx = torch.empty_like(xd)
+    w1 = torch.zeros(C, device=dev); w2 = torch.zeros(C, device=dev)
+    dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
+    ops.bn_train_bwd(xd, dzd, dx, mean, invstd, gamma.to(dev), beta.to(dev), 1, w1, w2, dgam, dbet)
+    torch.cuda.synchronize()
+    tol = _tol(dtype, stored=True)
+    torch.testing.assert_close(y.cpu().double(), yr.detach(), **tol)
+    torch.testing.assert_close(rm_d.cpu().double(), rmr, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv_d.cpu().double(), rvr, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx.cpu().double(), xr.grad, **tol)
+    gs = max(1.0, float(gr.grad.abs().max()))
+    torch.testing.assert_close(dgam.cpu().double(), gr.grad, rtol=1e-3, atol=1e-3 * gs)
+    torch.testing.assert_close(dbet.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * gs)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [128, 256])
+def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, C):
+    ops = _ops()
+    dev = gpu_device
+    B, G, levels = 3, 32, [(6, 6), (3, 3), (2, 2), (1, 1)]
+    g = torch.Generator().manual_seed(C)
+    xs = [round_to(torch.randn(B, C, h, w, generator=g) * 1.5 + 0.2, dtype) for (h, w) in levels]
+    dzs = [round_to(torch.randn(B, C, h, w, generator=g), dtype) for (h, w) in levels]
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    refs, xrs = [], []
+    for x, dz in zip(xs, dzs):
+        xr = x.double().requires_grad_(True)
+        yr = F.relu(F.group_norm(xr, G, gr, br, 1e-5))
+        yr.backward(dz.double())
+        refs.append(yr.detach()); xrs.append(xr)
+    hw = [h * w for (h, w) in levels]
+    xp = pack_levels(xs, dtype).to(dev); dzp = pack_levels(dzs, dtype).to(dev)
+    y = torch.empty_like(xp); dx = torch.empty_like(xp)
+    stats = torch.empty(len(levels) * B * G * 2, device=dev)
+    gsum = torch.empty_like(stats)
+    dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
+    ops.gn_relu_fwd(xp, y, hw, B, G, gamma.to(dev), beta.to(dev), 1e-5, stats)
+    ops.gn_relu_bwd(xp, dzp, dx, hw, B, G, gamma.to(dev), beta.to(dev), stats, gsum, dgam, dbet)
+    torch.cuda.synchronize()
+    tol = _tol(dtype, stored=True)
+    for gl, ref in zip(unpack_levels(y.cpu(), B, levels), refs):
+        torch.testing.assert_close(gl.double(), ref, **tol)
+    for gl, xr in zip(unpack_levels(dx.cpu(), B, levels), xrs):
+        torch.testing.assert_close(gl.double(), xr.grad, rtol=tol["rtol"], atol=3 * tol["atol"])
+    gs = max(1.0, float(gr.grad.abs().max()))
+    torch.testing.assert_close(dgam.cpu().double(), gr.grad, rtol=1e-3, atol=1e-3 * gs)
+    torch.testing.assert_close(dbet.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * gs)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pool_upsample_eltwise(gpu_device, dtype):
+    ops = _ops()
+    dev = gpu_device
+    B, C, H, W = 2, 16, 8, 6
+    g = torch.Generator().manual_seed(5)
+    x = round_to(torch.randn(B, C, H, W, generator=g), dtype)
+    x[0, :, 0:2, 0:2] = 1.0   # ties: gradient must go to the first max (torch order)
+    dy = round_to(torch.randn(B, C, H // 2, W // 2, generator=g), dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    yr.backward(dy)
+    xp = pack_levels([x], dtype).to(dev)
+    y = torch.empty(B * (H // 2) * (W // 2), C, dtype=dtype, device=dev)
+    ops.maxpool2_fwd(xp, y, B, H, W)
+    dx = torch.empty_like(xp)
+    ops.maxpool2_bwd(xp, pack_levels([dy], dtype).to(dev), dx, B, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(unpack_levels(y.cpu(), B, [(H // 2, W // 2)])[0], yr.detach())
+    assert torch.equal(unpack_levels(dx.cpu(), B, [(H, W)])[0], xr.grad)
+    # upsample + add and its adjoint
+    coarse = round_to(torch.randn(B, C, H // 2, W // 2, generator=g), dtype)
+    out = torch.empty_like(xp)
+    ops.upsample2_add(xp, pack_levels([coarse], dtype).to(dev), out, B, H, W)
+    ref = x + F.interpolate(coarse, scale_factor=2, mode="nearest")
+    dco = torch.empty(B * (H // 2) * (W // 2), C, dtype=dtype, device=dev)
+    ops.sumpool2(xp, dco, B, H, W)
+    torch.cuda.synchronize()
+    tol = _tol(dtype, stored=True)
+    torch.testing.assert_close(unpack_levels(out.cpu(), B, [(H, W)])[0], ref, **tol)
+    torch.testing.assert_close(unpack_levels(dco.cpu(), B, [(H // 2, W // 2)])[0],
+                               F.avg_pool2d(x, 2) * 4, **tol)
+    # relu / relu-bwd / add
+    r = torch.empty_like(xp)
+    ops.eltwise(ops.ELT_RELU, xp, None, r)
+    rb = torch.empty_like(xp)
+    ops.eltwise(ops.ELT_RELU_BWD, xp, out, rb)
+    torch.cuda.synchronize()
+    assert torch.equal(r.cpu().float(), F.relu(xp.cpu().float()))
+    assert torch.equal(rb.cpu().float(), torch.where(xp.cpu().float() > 0, out.cpu().float(), torch.zeros(())))
+    img = torch.randn(2, 3, 5, 7, generator=g)
+    nh = ops.image_to_nhwc(img.to(dev), dtype)
+    torch.cuda.synchronize()
+    got = nh.cpu().float().reshape(2, 5, 7, 8)
+    torch.testing.assert_close(got[..., :3], round_to(img, dtype).permute(0, 2, 3, 1))
+    assert float(got[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("reach", [0.5, None])
+def test_sinkhorn_kernel_vs_oracle(gpu_device, reach):
+    """fp32 kernel vs fp64 oracle: loss rtol 1e-4, grads rtol 2e-3."""
+    ops = _ops()
+    from oracle.sinkhorn_ref import kd_loss_images
+    r = np.random.default_rng(0)
+    counts_s = [10, 0, 9, 12, 1, 10]
+    counts_t = [10, 7, 0, 9, 3, 10]
+    P, M = sum(counts_s), sum(counts_t)
+    # LINEMOD-like: clustered votes around 8 keypoints, normalised coordinates
+    centres = r.uniform(0.3, 0.7, (8, 2))
+    xs = (centres[None] + r.normal(0, 0.02, (P, 8, 2))).astype(np.float32)
+    yt = (centres[None] + r.normal(0, 0.01, (M, 8, 2))).astype(np.float32)
+    al = np.repeat(r.uniform(0.05, 0.95, (P, 1)), 8, 1).astype(np.float32)
+    be = np.repeat(r.uniform(0.2, 0.99, (M, 1)), 8, 1).astype(np.float32)
+    if reach is None:
+        al /= al.sum(0, keepdims=True); be /= be.sum(0, keepdims=True)
+    s_off = np.concatenate([[0], np.cumsum(counts_s)]).astype(np.int32)
+    t_off = np.concatenate([[0], np.cumsum(counts_t)]).astype(np.int32)
+    blur = 0.001 if reach else 0.01
+    if reach is None:
+        # balanced problems need equal masses per image
+        for i in range(len(counts_s)):
+            a = slice(s_off[i], s_off[i + 1]); b = slice(t_off[i], t_off[i + 1])
+            if counts_s[i] and counts_t[i]:
+                al[a] /= al[a].sum(0, keepdims=True); be[b] /= be[b].sum(0, keepdims=True)
+    loss_r, valid_r, gx_r, ga_r = kd_loss_images(xs.astype(np.float64), al.astype(np.float64), s_off,
+                                                 yt.astype(np.float64), be.astype(np.float64), t_off,
+                                                 blur=blur, scaling=0.5, reach=reach)
+    dev = gpu_device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    loss, valid, gx, ga = ops.sinkhorn_div(t(xs), t(al), t(s_off), t(yt), t(be), t(t_off), len(counts_s),
+                                           2.0, blur, 0.5, reach)
+    torch.cuda.synchronize()
+    assert valid.cpu().tolist() == valid_r.tolist()
+    np.testing.assert_allclose(loss.cpu().numpy(), loss_r, rtol=1e-4, atol=1e-7)
+    gscale = np.abs(gx_r).max()
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_r, rtol=2e-3, atol=2e-3 * gscale)
+    np.testing.assert_allclose(ga.cpu().numpy(), ga_r, rtol=2e-3, atol=2e-3 * np.abs(ga_r).max())
