@@ -1,0 +1,224 @@
+"""KD train-step throughput on MI355X (BASELINE.json metric) -- driver contract in the task brief.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = teacher (Darknet-53, frozen, eval) forward + teacher cell selection + student
+(Darknet-tiny-H, train) forward + focal / object-space / Sinkhorn-OT losses + backward +
+(RCCL mean all-reduce of the flat gradient bucket) + fused clip + AdamW + OneCycle, on a seeded
+synthetic LINEMOD-shaped batch (640x480 frame geometry, 256x256 DZI crops: what the reference
+actually feeds the network), B = 16 images per GPU, inputs resident in HBM.
+
+The single JSON line carries, besides the contract fields:
+  roofline     -- dominant kernel = the implicit-GEMM convolution (all launches of
+                  kd6d_conv2d_{fwd,dgrad,wgrad} in a step): algorithmic FLOPs (2*MAC on the
+                  reference's channel counts) / summed launch durations measured with HIP events
+                  on the launch stream in instrumented steps after the timed region
+                  (DESIGN.md "Measurement"); peak = 2.5 PFLOP/s dense bf16 MFMA.
+  cpu_baseline -- oracle/kd_step_ref.py (pure-torch fp32 port of the reference step, validated
+                  against the imported reference) timed on this host's cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "kd-6d-pose-adlp_amd"))
+
+import torch  # noqa: E402
+
+FLOP_PER_IMG = {  # teacher fwd + 3 x student fwd, 2*MAC of all convs
+    ("darknet_tiny_h", 256): 49.2e9, ("darknet_tiny", 256): 86.9e9,
+    ("darknet_tiny_h", 640): 230.6e9, ("darknet_tiny", 640): 407.4e9,
+}
+PEAK_BF16 = 2.5e15
+PEAK_F32 = 157.3e12
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--batch", type=int, default=16, help="images per GPU")
+    p.add_argument("--student", type=str, default="darknet_tiny_h")
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--frame", type=str, default="crop256", choices=["crop256", "full640"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=4)
+    return p.parse_args()
+
+
+def make_cfg(arch, precision):
+    import yaml
+    from kd6d.arguments.argument import custom_cfg
+    with open(os.path.join(HERE, "configs", "ape.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["RUNTIME"] = {"PRECISION": precision}
+    cfg["MODEL"]["BACKBONE"] = arch
+    cfg = custom_cfg(cfg)
+    cfg["KD"] = dict(LOSS_WEIGHT_KD=5.0, LEVEL="pred", GLEVEL="point", GTYPE="sinkhorn", GP=2.0, GBLUR=0.001, GnD=2,
+                     WEIGHTED_OT=True, DETACH=False, SCALING=0.5, REACH=0.5)
+    return cfg
+
+
+TEACHER_CLS_BIAS = [1.0] + [-6.0] * 14
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the kd6d step has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from kd6d import backbone as BB, ops
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs import distributed as D
+    from kd6d.models.model_kd import PoseModuleKD
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import make_batch
+
+    teacher = PoseModuleKD(make_cfg("darknet53", args.precision), BB.darknet53())
+    teacher.net.reset_parameters(seed=2)
+    with torch.no_grad():
+        sd = teacher.state_dict()
+        sd["head.cls_logits.bias"] = torch.tensor(TEACHER_CLS_BIAS)
+        # random-init BN statistics: make the frozen teacher's activations well-scaled
+        teacher.load_state_dict(sd)
+    teacher = teacher.to(dev).eval()
+    student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
+    student.net.reset_parameters(seed=1)
+    student = student.to(dev).train()
+    if world > 1:
+        D.broadcast_(student.net.store.params, 0)
+        student.net.invalidate()
+    base_lr = 1e-3 / world                      # libs/train_libs.py:117
+    opt = FusedClipAdamW(student, lr=base_lr, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, base_lr, 10100, pct_start=0.05, cycle_momentum=False,
+                                                anneal_strategy="linear")
+    full = args.frame == "full640"
+    B = args.batch
+    batches = []
+    for i in range(4):
+        images, targets = make_batch(B, 1000 * rank + i, full_frame=full)
+        batches.append((images.to(dev), PackedTargets(targets, dev)))
+
+    def step(i):
+        images, tgt = batches[i % len(batches)]
+        student.zero_grad()
+        with torch.no_grad():
+            pred_t = teacher(images, targets=tgt, is_teacher=True)
+        _, ld = student(images, targets=tgt, pred_t=pred_t)
+        loss = ld["loss_cls"] * 0.1 + ld["loss_reg"] * 1.0 + ld["loss_kd"] * 5.0
+        loss.backward()
+        opt.step()
+        sched.step()
+        return ld
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ld = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = {k: float(v) for k, v in ld.items()}
+    finite = all(v == v and abs(v) != float("inf") for v in losses.values())
+
+    # ---- roofline leg: per-launch HIP-event timing of every conv launch, in instrumented steps that
+    # every rank runs (the step contains the gradient all-reduce) but only rank 0 records ----
+    n_instr = 3
+    if rank == 0:
+        ops.profile_begin()
+    for i in range(n_instr):
+        step(args.warmup + args.steps + i)
+    rec = ops.profile_end() if rank == 0 else []
+
+    out = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        size = 640 if full else 256
+        flop_img = FLOP_PER_IMG.get((args.student, size))
+        conv = [(k, f, ms_) for (k, f, ms_) in rec if k.startswith("conv")]
+        tot_flop = sum(f for _, f, _ in conv)
+        tot_ms = sum(m for _, _, m in conv)
+        by_kind = {}
+        for k, f, m in conv:
+            a = by_kind.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += f; a[2] += m
+        peak = PEAK_BF16 if args.precision == "bf16" else PEAK_F32
+        achieved = tot_flop / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_igemm (fwd+dgrad+wgrad, all launches of a step)",
+                "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": None, "launches_per_step": len(conv) // n_instr,
+                "avg_launch_us": 1e3 * tot_ms / max(len(conv), 1),
+                "conv_ms_per_step": tot_ms / n_instr, "flop_per_step": tot_flop / n_instr,
+                "by_kind": {k: {"launches_per_step": v[0] // n_instr, "tflops": v[1] / (v[2] * 1e-3) / 1e12 if v[2] else 0,
+                                "ms_per_step": v[2] / n_instr} for k, v in by_kind.items()},
+                "step_algorithmic_tflops": (value * flop_img / 1e12) if flop_img else None}
+        out = {"metric": "KD train-step images/sec (teacher+student fwd + OT loss + bwd + AdamW)", "value": value,
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+               "data": "synthetic",
+               "config": {"workload": "Ape KD: darknet53 teacher -> %s student, kd_weight=5, %s, batch=%d/GPU, "
+                                      "%s" % (args.student, args.precision, B,
+                                              "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
+                          "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
+               "losses_last_step": losses, "finite": finite, "roofline": roof}
+        # ---- CPU baseline leg (oracle = port of the reference step), rank 0, N=1 only ----
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, B, full)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(args, B, full):
+    from kd6d.synthetic import INTERNAL_K, MESH_DIAMETERS, make_batch
+    from oracle import kd_step_ref as O
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(cores)
+    stepper = O.KDStepRef(args.student, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0,
+                          teacher_cls_bias=TEACHER_CLS_BIAS)
+    images, targets = make_batch(B, 0, full_frame=full)
+    td = [t.as_dict() for t in targets]
+    stepper.step(images.tensors, td)                      # warm-up
+    n = max(1, args.cpu_steps)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        stepper.step(images.tensors, td)
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same B=%d step after 1 warm-up (oracle/kd_step_ref.py, torch fp32, %d threads)"
+                      % (n, B, cores), "ms_per_step": dt / n * 1e3}
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,131 @@ int kd6d_pack_dgrad_weights(int dtype, const void* w_base, void* wt_base,
                             const int32_t* desc_dev, int n_layers,
                             int total_blocks, void* stream);
 
+
+/* Pyramid description for the loss-side kernels: level l has an h[l] x w[l] grid of cells,
+ * anchor stride / size as in configs/ape.yaml:3-4; rows are packed level-major, then image. */
+typedef struct kd6d_levels {
+  int32_t n;
+  int32_t batch;
+  int32_t h[KD6D_MAX_SEG];
+  int32_t w[KD6D_MAX_SEG];
+  float anchor_stride[KD6D_MAX_SEG];
+  float anchor_size[KD6D_MAX_SEG];   /* all 5 entries are read by teacher_select (postprocess_kd.py:143) */
+} kd6d_levels;
+
+#define KD6D_MAX_GT 4   /* instances per image handled by the assignment kernel */
+
+int kd6d_device_cu_count(void);
+
+/* ---- normalisation / pooling (HBM-bound, 16-B granules) ------------------------------------
+ * BatchNorm2d(train)+LeakyReLU of ConvBlock (backbone/common.py:316-324): batch statistics by
+ * kd6d_colstats (per-channel sum / sum of squares, fp32 atomics into pre-zeroed buffers), then
+ * kd6d_bn_train_fwd normalises, updates running stats (momentum 0.1, unbiased var) and saves
+ * mean / invstd for the backward pair.  x_f32 != 0: the pre-normalisation tensor x is fp32 while
+ * activations/gradients are `dtype` (keeps (x - mean) free of bf16 cancellation error). */
+int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum, float* sumsq, void* stream);
+int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows, int C, const float* sum,
+                      const float* sumsq, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                      int act, void* stream);
+int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, const void* dz, int64_t rows, int C,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             int act, float* sum_dy, float* sum_dy_xhat, void* stream);
+int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            int act, const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
+                            float* dbeta, void* stream);
+
+/* GroupNorm(groups)+ReLU of the PoseHead towers (models/model.py:395-417) over a multi-level
+ * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 floats per
+ * (level, image, group) = {mean, rstd}; gsum_ws: workspace of the same size. */
+int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host, int nseg, int batch,
+                     int C, int groups, const float* gamma, const float* beta, float eps, float* stats,
+                     void* stream);
+int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, const int32_t* level_hw_host,
+                     int nseg, int batch, int C, int groups, const float* gamma, const float* beta,
+                     const float* stats, float* gsum_ws, float* dgamma, float* dbeta, void* stream);
+
+/* MaxPool2d(2,2) (backbone/darknet.py:94-97), nearest-x2 upsample + add (models/model.py:75-78)
+ * and its adjoint, ReLU / ReLU-backward / add (mode 0/1/2), NCHW fp32 image -> padded NHWC. */
+int kd6d_maxpool2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
+int kd6d_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H, int W, int C,
+                      int accumulate, void* stream);
+int kd6d_upsample2_add(int dtype, const void* fine, const void* coarse, void* out, int B, int H, int W,
+                       int C, void* stream);
+int kd6d_sumpool2(int dtype, const void* dfine, void* dcoarse, int B, int H, int W, int C, int accumulate,
+                  void* stream);
+int kd6d_eltwise(int dtype, int mode, const void* x, const void* dy, void* y, int64_t n_elems, void* stream);
+int kd6d_image_to_nhwc(int dtype, const float* img_nchw, void* out, int B, int Cimg, int H, int W, int Cpad,
+                       void* stream);
+
+/* ---- optimal-transport KD loss: replaces geomloss.SamplesLoss("sinkhorn", p=2, blur, scaling,
+ * reach) as called from losses/loss_libs.py:22-51 (one call per image, batch dim = 8 keypoints)
+ * and its autograd.  Image b uses student points xs[(s_start[b]+i)*8+k][2] (i < s_cnt[b]) with
+ * weights alpha[(..)*8+k] and teacher points/weights likewise; reach <= 0 means balanced.
+ * Outputs: loss_img[b] = sum_k S_k (0 when a set is empty: valid_img[b] = 0; -1 = set larger than
+ * kd6d_sinkhorn_max_points()), grad_xs / grad_alpha = d loss_img / d xs, alpha. */
+int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, const int32_t* s_start,
+                              const int32_t* s_cnt, const float* yt, const float* beta,
+                              const int32_t* t_start, const int32_t* t_cnt, int n_images, float p, float blur,
+                              float scaling, float reach, float* loss_img, int32_t* valid_img, float* grad_xs,
+                              float* grad_alpha, void* stream);
+int kd6d_sinkhorn_max_points(void);
+
+/* ---- loss-side kernels (cls logits (rows,16) fp32 [15 classes + pad], reg logits (rows,240)) --
+ * kd6d_teacher_select  <- postprocess/postprocess_kd.py:22-203 (PnP gate treated as true):
+ *   slot layout: image b owns slots [b*cap, b*cap + t_cnt[b]); t_kp (slots,8,2) full-frame px,
+ *   t_score (slots,8) = sqrt(sigmoid), t_row = packed row of the chosen cell; t_kp_norm =
+ *   t_kp / (frame_w, frame_h) and t_beta = t_score^2 are the OT inputs (loss_libs.py:8-12,
+ *   kd_loss.py:82).
+ * kd6d_ssc_assign      <- losses/loss.py:164-268; per-image inputs are padded to KD6D_MAX_GT
+ *   instances; keys (rows) are caller-supplied uniform randoms (the n smallest in-mask keys per
+ *   level are the reference's randperm(...)[:n]).  labels (rows): -1 ignore, 0 bg, c+1.
+ * kd6d_focal_fwd/bwd   <- losses/loss.py:20-40 (sum reduction; bwd writes ALL of dcls).
+ * kd6d_student_points  <- losses/kd_loss.py:40-71,152: decoded full-frame keypoints of the
+ *   positive cells (normalised by frame_w/h into xs), OT weights alpha, loss_reg (+=) and its
+ *   gradient w.r.t. the full-frame points.
+ * kd6d_kd_mean         <- kd_loss.py:99-103.
+ * kd6d_loss_backward   <- autograd of the above into dcls (+=) / dreg (positive rows only). */
+int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, const float* reg,
+                        const float* bbox_trans, float threshold, float positive_num, float positive_lambda,
+                        int cap, float frame_w, float frame_h, int32_t* t_cnt, float* t_kp, float* t_score,
+                        int32_t* t_row, float* t_kp_norm, float* t_beta, void* stream);
+int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int mask_h, int mask_w, const float* kp3d,
+                    const float* K, const int32_t* class_ids, const int32_t* n_gt, const float* rot,
+                    const float* trans, const float* bbox_trans, const float* keys, float positive_num,
+                    float positive_lambda, int cap, int32_t* labels, int32_t* pos_cnt, int32_t* pos_row,
+                    int32_t* pos_gt, void* stream);
+int kd6d_focal_fwd(const float* cls, const int32_t* labels, int rows, float gamma, float alpha, float* loss,
+                   void* stream);
+int kd6d_focal_bwd(int dtype, const float* cls, const int32_t* labels, int rows, float gamma, float alpha,
+                   const float* weight, void* dcls, void* stream);
+int kd6d_student_points(const kd6d_levels* levels, const float* cls, const float* reg, const int32_t* pos_cnt,
+                        const int32_t* pos_row, const int32_t* pos_gt, const int32_t* class_ids,
+                        const float* kp3d, const float* rot, const float* trans, const float* bbox_trans,
+                        const float* diameters, const float* kinv_host, float frame_w, float frame_h, int cap,
+                        float* xs, float* alpha, float* g_reg_xy, float* loss_reg, int32_t* s_start,
+                        void* stream);
+int kd6d_kd_mean(const float* loss_img, const int32_t* valid_img, int n_images, float* loss_kd,
+                 int32_t* n_valid, void* stream);
+int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const float* cls, const float* reg,
+                       const int32_t* pos_cnt, const int32_t* pos_row, const int32_t* pos_gt,
+                       const int32_t* class_ids, const float* bbox_trans, const float* g_reg_xy,
+                       const float* g_kd_xs, const float* g_kd_alpha, const int32_t* n_valid,
+                       const int32_t* valid_img, const float* weights, const float* seg_scale,
+                       float* dseg_scale, float frame_w, float frame_h, int cap, int detach_alpha, void* dcls,
+                       void* dreg, void* stream);
+
+/* ---- optimiser: replaces clip_grad_norm_ + AdamW.step of train_kd.py:138-139 on one flat buffer.
+ * kd6d_sumsq accumulates sum(x^2) into *out (pre-zeroed); kd6d_clip_adamw applies
+ * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update
+ * (torch.optim.AdamW semantics, step counted from 1) and refreshes the bf16 shadow if given. */
+int kd6d_sumsq(const float* x, int64_t n, float* out, void* stream);
+int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    const float* gnorm_sq, double max_norm, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step, void* bf16_shadow, void* stream);
+int kd6d_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

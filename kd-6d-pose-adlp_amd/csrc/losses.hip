@@ -1,0 +1,700 @@
+// Loss-side kernels of the KD step: teacher knowledge extraction, SSC target assignment,
+// focal loss, object-space keypoint loss, and the scatter of loss gradients back into the
+// head's logit-gradient tensors.  The reference runs these as Python loops with one or more
+// device->host syncs per image; here each is one launch for the batch and nothing syncs.
+//
+//   teacher_select   <- postprocess/postprocess_kd.py:22-203 (PnP gate treated as true)
+//   ssc_assign       <- losses/loss.py:164-268 (random pick = n smallest of caller-supplied keys)
+//   focal fwd/bwd    <- losses/loss.py:20-40
+//   student_points   <- losses/kd_loss.py:40-71,152 + models/model.py:144-166 (decode + reg loss)
+//   loss_backward    <- autograd of kd_loss.py:47-86 and loss_libs.py:8-12 (chain into logits)
+//
+// Logit layout: cls (rows,16) fp32 [15 classes + 1 pad], reg (rows,240) fp32, rows packed
+// level-major / image / row-major (the conv kernels' packed NHWC order).
+#include "kd6d_common.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+struct Levels {
+  int n, batch;
+  int h[KD6D_MAX_SEG], w[KD6D_MAX_SEG], row0[KD6D_MAX_SEG];
+  float stride[KD6D_MAX_SEG], size[KD6D_MAX_SEG];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// (value, index) arg-max over the workgroup; ties -> smallest index.  All threads get the result.
+__device__ __forceinline__ void block_argmax(float& v, int& idx, float* s_v, int* s_i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_i[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  v = s_v[0]; idx = s_i[0];
+  for (int w = 1; w < kT / 64; ++w)
+    if (s_v[w] > v || (s_v[w] == v && s_i[w] < idx)) { v = s_v[w]; idx = s_i[w]; }
+}
+
+__device__ __forceinline__ void level_fields(const Levels& L, int l, int& h, int& w, int& row0,
+                                             float& stride, float& size) {
+  h = 0; w = 0; row0 = 0; stride = 1.f; size = 1.f;
+#pragma unroll
+  for (int s = 0; s < KD6D_MAX_SEG; ++s)
+    if (s == l) { h = L.h[s]; w = L.w[s]; row0 = L.row0[s]; stride = L.stride[s]; size = L.size[s]; }
+}
+
+__device__ __forceinline__ void inv2x2(const float* bt, float* ai) {
+  const float a = bt[0], b = bt[1], c = bt[3], d = bt[4];
+  const float det = a * d - b * c;
+  ai[0] = d / det; ai[1] = -b / det; ai[2] = -c / det; ai[3] = a / det;
+}
+
+// ------------------------------------------------------------------------------------
+// Teacher knowledge extraction: one workgroup per image.
+// out: t_cnt[b]; t_kp[(b*cap + slot)*16 + k*2 + {0,1}] full-frame px; t_score[(b*cap+slot)*8 + k]
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void teacher_select_kernel(
+    const float* __restrict__ cls, const float* __restrict__ reg, Levels L,
+    const float* __restrict__ bbox_trans, float th, float positive_num, float positive_lambda, int cap,
+    float frame_w, float frame_h, int* __restrict__ t_cnt, float* __restrict__ t_kp,
+    float* __restrict__ t_score, int* __restrict__ t_row, float* __restrict__ t_kp_norm,
+    float* __restrict__ t_beta) {
+  __shared__ float s_v[kT / 64];
+  __shared__ int s_i[kT / 64];
+  __shared__ unsigned s_mask;
+  __shared__ int s_nk[KD6D_MAX_SEG];
+  __shared__ int s_total;
+  const int b = blockIdx.x;
+  const float logit_th = logf(th / (1.f - th));
+
+  // classes with at least one candidate cell
+  if (threadIdx.x == 0) s_mask = 0u;
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int l = 0; l < L.n; ++l) {
+    int h, w, row0; float st, sz;
+    level_fields(L, l, h, w, row0, st, sz);
+    const int hw = h * w;
+    for (int e = threadIdx.x; e < hw * 15; e += kT) {
+      const int cell = e / 15, c = e - cell * 15;
+      const float x = cls[(size_t)(row0 + b * hw + cell) * 16 + c];
+      if (sigmoidf_(x) > th) mine |= 1u << c;
+    }
+  }
+  if (mine) atomicOr(&s_mask, mine);
+  __syncthreads();
+  const unsigned cmask = s_mask;
+  (void)logit_th;
+
+  float ai[4];
+  inv2x2(bbox_trans + b * 6, ai);
+  const float tx = bbox_trans[b * 6 + 2], ty = bbox_trans[b * 6 + 5];
+
+  int emitted = 0;
+  for (int c = 0; c < 15 && emitted == 0; ++c) {
+    if (!((cmask >> c) & 1u)) continue;
+    // ---- most confident cell per level -> reference box size (postprocess_kd.py:121-141) ----
+    float box_conf = 0.f, box_size = 0.f;
+    for (int l = 0; l < L.n; ++l) {
+      int h, w, row0; float st, sz;
+      level_fields(L, l, h, w, row0, st, sz);
+      const int hw = h * w;
+      float bv = -1.f; int bi = 0x7fffffff;
+      for (int cell = threadIdx.x; cell < hw; cell += kT) {
+        const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
+        if (p > th) {
+          const float s = sqrtf(p);
+          if (s > bv || (s == bv && cell < bi)) { bv = s; bi = cell; }
+        }
+      }
+      block_argmax(bv, bi, s_v, s_i);
+      if (bv > 0.f && bv > box_conf) {
+        box_conf = bv;
+        const float* r = reg + (size_t)(row0 + b * hw + bi) * 240 + c * 16;
+        const float cx = (float)(bi % w) * st + st * 0.5f, cy = (float)(bi / w) * st + st * 0.5f;
+        float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+        for (int k = 0; k < 8; ++k) {
+          const float px = r[k] * sz + cx, py = r[8 + k] * sz + cy;
+          mnx = fminf(mnx, px); mxx = fmaxf(mxx, px); mny = fminf(mny, py); mxy = fmaxf(mxy, py);
+        }
+        const float size = fmaxf(mxx - mnx, mxy - mny);
+        if (size > box_size) box_size = size;
+      }
+    }
+    // ---- cells per level: int(P * w_l / sum w + .5) over ALL anchor sizes (:143-146) ----
+    if (threadIdx.x == 0) {
+      float wl[KD6D_MAX_SEG], sum = 0.f;
+      for (int l = 0; l < KD6D_MAX_SEG; ++l) {
+        const float sz = L.size[l] > 0.f ? L.size[l] : 32.f * (float)(1 << l);
+        const float dk = log2f(box_size / sz);
+        wl[l] = expf(-positive_lambda * dk * dk);
+        sum += wl[l];
+      }
+      for (int l = 0; l < KD6D_MAX_SEG; ++l) s_nk[l] = (int)(positive_num * wl[l] / sum + 0.5f);
+      s_total = 0;
+    }
+    __syncthreads();
+    // ---- top-n_l per level, score descending -------------------------------------------
+    for (int l = 0; l < L.n; ++l) {
+      int h, w, row0; float st, sz;
+      level_fields(L, l, h, w, row0, st, sz);
+      const int hw = h * w;
+      const int want = s_nk[l];
+      float last_v = INFINITY; int last_i = -1;
+      for (int t = 0; t < want; ++t) {
+        float bv = -1.f; int bi = 0x7fffffff;
+        for (int cell = threadIdx.x; cell < hw; cell += kT) {
+          const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
+          if (p > th) {
+            const float s = sqrtf(p);
+            const bool after = (s < last_v) || (s == last_v && cell > last_i);
+            if (after && (s > bv || (s == bv && cell < bi))) { bv = s; bi = cell; }
+          }
+        }
+        block_argmax(bv, bi, s_v, s_i);
+        if (bv <= 0.f) break;          // fewer candidates than n_l
+        last_v = bv; last_i = bi;
+        const int slot = s_total;      // uniform: written only after the barrier below
+        if (slot < cap && threadIdx.x < 8) {
+          const int k = threadIdx.x;
+          const int row = row0 + b * hw + bi;
+          const float* r = reg + (size_t)row * 240 + c * 16;
+          const float cx = (float)(bi % w) * st + st * 0.5f, cy = (float)(bi / w) * st + st * 0.5f;
+          const float px = r[k] * sz + cx - tx, py = r[8 + k] * sz + cy - ty;
+          const size_t o = (size_t)(b * cap + slot);
+          const float fx = ai[0] * px + ai[1] * py, fy = ai[2] * px + ai[3] * py;
+          t_kp[o * 16 + k * 2 + 0] = fx;
+          t_kp[o * 16 + k * 2 + 1] = fy;
+          t_score[o * 8 + k] = bv;
+          // OT inputs (loss_libs.py:8-12 normalisation, kd_loss.py:82 weight = score^2)
+          t_kp_norm[o * 16 + k * 2 + 0] = fx / frame_w;
+          t_kp_norm[o * 16 + k * 2 + 1] = fy / frame_h;
+          t_beta[o * 8 + k] = bv * bv;
+          if (k == 0) t_row[o] = row;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_total = slot + 1;
+        __syncthreads();
+      }
+    }
+    emitted = s_total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) t_cnt[b] = emitted < cap ? emitted : cap;
+}
+
+// ------------------------------------------------------------------------------------
+// SSC target assignment: one workgroup per image.
+// ------------------------------------------------------------------------------------
+constexpr int kMaxGt = 4;
+
+__global__ __launch_bounds__(kT) void ssc_assign_kernel(
+    Levels L, const float* __restrict__ mask, int mh, int mw, const float* __restrict__ kp3d,
+    const float* __restrict__ Kmat, const int* __restrict__ class_ids, const int* __restrict__ n_gt,
+    const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ bbox_trans, const float* __restrict__ keys, float positive_num,
+    float positive_lambda, int cap, int* __restrict__ labels, int* __restrict__ pos_cnt,
+    int* __restrict__ pos_row, int* __restrict__ pos_gt) {
+  __shared__ float s_v[kT / 64];
+  __shared__ int s_i[kT / 64];
+  __shared__ int s_has[kMaxGt];
+  __shared__ float s_span[kMaxGt];
+  __shared__ int s_total;
+  __shared__ int s_sel_row[64];
+  __shared__ int s_sel_gt[64];
+  const int b = blockIdx.x;
+  int G = n_gt[b];
+  if (G > kMaxGt) G = kMaxGt;
+  const float* m = mask + (size_t)b * mh * mw;
+
+  if (threadIdx.x < kMaxGt) s_has[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
+  // which instances are present in the mask (poses.py:269-278)
+  {
+    int has[kMaxGt] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < mh * mw; i += kT) {
+      const float v = m[i];
+#pragma unroll
+      for (int g = 0; g < kMaxGt; ++g) has[g] |= (v == (float)(g + 1));
+    }
+#pragma unroll
+    for (int g = 0; g < kMaxGt; ++g)
+      if (has[g]) atomicOr(&s_has[g], 1);
+  }
+  __syncthreads();
+  // projected 3D-bbox span in crop coordinates (poses.py:280-300, boxlist.py:229-239)
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    float span = 1.f;  // box [0,0,0,0] -> span 1
+    if (s_has[g]) {
+      const int c = class_ids[b * kMaxGt + g];
+      const float* X = kp3d + ((size_t)b * 15 + c) * 24;
+      const float* R = rot + ((size_t)b * kMaxGt + g) * 9;
+      const float* T = trans + ((size_t)b * kMaxGt + g) * 3;
+      const float* Kk = Kmat + (size_t)b * 9;
+      const float* bt = bbox_trans + (size_t)b * 6;
+      float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+      for (int k = 0; k < 8; ++k) {
+        float cam[3];
+        for (int r = 0; r < 3; ++r)
+          cam[r] = R[r * 3 + 0] * X[k * 3 + 0] + R[r * 3 + 1] * X[k * 3 + 1] + R[r * 3 + 2] * X[k * 3 + 2] + T[r];
+        float pr[3];
+        for (int r = 0; r < 3; ++r) pr[r] = Kk[r * 3 + 0] * cam[0] + Kk[r * 3 + 1] * cam[1] + Kk[r * 3 + 2] * cam[2];
+        const float u = pr[0] / (pr[2] + 1e-8f), v = pr[1] / (pr[2] + 1e-8f);
+        const float x = bt[0] * u + bt[1] * v + bt[2], y = bt[3] * u + bt[4] * v + bt[5];
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+      }
+      span = fmaxf(mxx - mnx + 1.f, mxy - mny + 1.f);
+    }
+    s_span[g] = span;
+  }
+  __syncthreads();
+
+  // labels pass 1: -1 for every in-mask cell, 0 elsewhere (selected cells overwritten below)
+  for (int l = 0; l < L.n; ++l) {
+    int h, w, row0; float st, sz;
+    level_fields(L, l, h, w, row0, st, sz);
+    const int hw = h * w;
+    for (int cell = threadIdx.x; cell < hw; cell += kT) {
+      const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
+      const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
+      const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
+      const float v = m[iy * mw + ix];
+      int in_any = 0;
+      for (int g = 0; g < G; ++g) in_any |= (v == (float)(g + 1));
+      labels[row0 + b * hw + cell] = in_any ? -1 : 0;
+    }
+  }
+  __syncthreads();
+
+  // per level / per gt: the n_k in-mask cells with the smallest random keys (loss.py:217-231)
+  for (int l = 0; l < L.n; ++l) {
+    int h, w, row0; float st, sz;
+    level_fields(L, l, h, w, row0, st, sz);
+    const int hw = h * w;
+    for (int g = 0; g < G; ++g) {
+      float sum = 0.f, wl = 0.f;
+      for (int q = 0; q < L.n; ++q) {
+        const float dk = fabsf(log2f(s_span[g] / L.size[q]));
+        const float e = expf(-positive_lambda * dk * dk);
+        sum += e;
+        if (q == l) wl = e;
+      }
+      const int want = (int)(positive_num * wl / sum + 0.5f);
+      float last_v = INFINITY; int last_i = -1;   // keys are negated so arg-max picks the smallest key
+      for (int t = 0; t < want; ++t) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int cell = threadIdx.x; cell < hw; cell += kT) {
+          const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
+          const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
+          const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
+          if (m[iy * mw + ix] == (float)(g + 1)) {
+            const float s = -keys[row0 + b * hw + cell];
+            const bool after = (s < last_v) || (s == last_v && cell > last_i);
+            if (after && (s > bv || (s == bv && cell < bi))) { bv = s; bi = cell; }
+          }
+        }
+        block_argmax(bv, bi, s_v, s_i);
+        if (bi == 0x7fffffff) break;   // fewer in-mask cells than n_k
+        last_v = bv; last_i = bi;
+        if (threadIdx.x == 0) {
+          const int slot = s_total;
+          if (slot < 64) { s_sel_row[slot] = row0 + b * hw + bi; s_sel_gt[slot] = g; }
+          s_total = slot + 1;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  // emit positives in ascending row order (the reference's nonzero() order) and their labels
+  if (threadIdx.x == 0) {
+    int n = s_total < 64 ? s_total : 64;
+    for (int i = 1; i < n; ++i) {
+      const int r = s_sel_row[i], g = s_sel_gt[i];
+      int j = i - 1;
+      while (j >= 0 && s_sel_row[j] > r) { s_sel_row[j + 1] = s_sel_row[j]; s_sel_gt[j + 1] = s_sel_gt[j]; --j; }
+      s_sel_row[j + 1] = r; s_sel_gt[j + 1] = g;
+    }
+    if (n > cap) n = cap;
+    pos_cnt[b] = n;
+    for (int i = 0; i < n; ++i) {
+      pos_row[b * cap + i] = s_sel_row[i];
+      pos_gt[b * cap + i] = s_sel_gt[i];
+      labels[s_sel_row[i]] = class_ids[b * kMaxGt + s_sel_gt[i]] + 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Sigmoid focal loss (sum) and its gradient.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void focal_fwd_kernel(const float* __restrict__ cls,
+                                                       const int* __restrict__ labels, int rows,
+                                                       float gamma, float alpha, float* loss) {
+  __shared__ float s_part[kT / 64];
+  float acc = 0.f;
+  const long long total = (long long)rows * 15;
+  for (long long e = (long long)blockIdx.x * kT + threadIdx.x; e < total; e += (long long)gridDim.x * kT) {
+    const int row = (int)(e / 15), c = (int)(e - (long long)row * 15);
+    const int t = labels[row];
+    if (t < 0) continue;
+    float p = sigmoidf_(cls[(size_t)row * 16 + c]);
+    p = fminf(fmaxf(p, 1e-4f), 1.f - 1e-4f);
+    if (t == c + 1) acc += -alpha * powf(1.f - p, gamma) * logf(p);
+    else acc += -(1.f - alpha) * powf(p, gamma) * logf(1.f - p);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kT / 64; ++w) s += s_part[w];
+    atomicAdd(loss, s);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kT) void focal_bwd_kernel(const float* __restrict__ cls,
+                                                       const int* __restrict__ labels, int rows,
+                                                       float gamma, float alpha,
+                                                       const float* __restrict__ weight,
+                                                       T* __restrict__ dcls) {
+  const float wgt = weight[0];
+  const long long total = (long long)rows * 16;
+  for (long long e = (long long)blockIdx.x * kT + threadIdx.x; e < total; e += (long long)gridDim.x * kT) {
+    const int row = (int)(e >> 4), c = (int)(e & 15);
+    const int t = labels[row];
+    float g = 0.f;
+    if (t >= 0 && c < 15) {
+      const float p0 = sigmoidf_(cls[e]);
+      if (p0 >= 1e-4f && p0 <= 1.f - 1e-4f) {
+        const float p = p0, q = 1.f - p0;
+        float dLdp;
+        if (t == c + 1) dLdp = alpha * (gamma * powf(q, gamma - 1.f) * logf(p) - powf(q, gamma) / p);
+        else dLdp = -(1.f - alpha) * (gamma * powf(p, gamma - 1.f) * logf(q) - powf(p, gamma) / q);
+        g = dLdp * p * q * wgt;
+      }
+    }
+    dcls[e] = from_f32<T>(g);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Student local predictions of the positive cells + object-space loss.
+// One workgroup per image, thread = (slot, keypoint).
+// ------------------------------------------------------------------------------------
+struct StudentArgs {
+  const float* cls; const float* reg;
+  const int* pos_cnt; const int* pos_row; const int* pos_gt;
+  const int* class_ids; const float* kp3d; const float* rot; const float* trans;
+  const float* bbox_trans; const float* diameters;
+  float kinv[9];
+  float frame_w, frame_h;
+  int cap;
+  float* xs; float* alpha; float* g_reg_xy; float* loss_reg; int* s_start;
+};
+
+__device__ __forceinline__ void locate_row(const Levels& L, int row, int& l, int& cell, int& w,
+                                           float& st, float& sz) {
+  l = 0; int r0 = 0, hw = 1; w = 1; st = 1.f; sz = 1.f;
+#pragma unroll
+  for (int s = 0; s < KD6D_MAX_SEG; ++s)
+    if (s < L.n && row >= L.row0[s]) { l = s; r0 = L.row0[s]; hw = L.h[s] * L.w[s]; w = L.w[s]; st = L.stride[s]; sz = L.size[s]; }
+  cell = (row - r0) % hw;
+}
+
+__global__ __launch_bounds__(kT) void student_points_kernel(Levels L, StudentArgs a) {
+  __shared__ float s_part[kT / 64];
+  const int b = blockIdx.x;
+  const int n = a.pos_cnt[b];
+  if (threadIdx.x == 0) a.s_start[b] = b * a.cap;
+  float ai[4];
+  inv2x2(a.bbox_trans + b * 6, ai);
+  const float tx = a.bbox_trans[b * 6 + 2], ty = a.bbox_trans[b * 6 + 5];
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < n * 8; e += kT) {
+    const int slot = e >> 3, k = e & 7;
+    const int row = a.pos_row[b * a.cap + slot];
+    const int g = a.pos_gt[b * a.cap + slot];
+    const int c = a.class_ids[b * kMaxGt + g];
+    int l, cell, w; float st, sz;
+    locate_row(L, row, l, cell, w, st, sz);
+    const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
+    const float* r = a.reg + (size_t)row * 240 + c * 16;
+    const float px = r[k] * sz + cx - tx, py = r[8 + k] * sz + cy - ty;
+    const float x = ai[0] * px + ai[1] * py, y = ai[2] * px + ai[3] * py;   // full-frame px
+    const size_t o = (size_t)(b * a.cap + slot) * 8 + k;
+    a.xs[o * 2 + 0] = x / a.frame_w;
+    a.xs[o * 2 + 1] = y / a.frame_h;
+    float p = sigmoidf_(a.cls[(size_t)row * 16 + c]);
+    a.alpha[o] = fminf(fmaxf(p, 1e-3f), 1.f - 1e-3f);
+    // ---- object-space loss (kd_loss.py:57-71) ----
+    const float* X3 = a.kp3d + ((size_t)b * 15 + c) * 24 + k * 3;
+    const float* R = a.rot + ((size_t)b * kMaxGt + g) * 9;
+    const float* T = a.trans + ((size_t)b * kMaxGt + g) * 3;
+    float X[3];
+    for (int i = 0; i < 3; ++i) X[i] = R[i * 3] * X3[0] + R[i * 3 + 1] * X3[1] + R[i * 3 + 2] * X3[2] + T[i];
+    float bb[3];
+    for (int i = 0; i < 3; ++i) bb[i] = a.kinv[i * 3] * x + a.kinv[i * 3 + 1] * y + a.kinv[i * 3 + 2];
+    const float bX = bb[0] * X[0] + bb[1] * X[1] + bb[2] * X[2];
+    const float b2 = bb[0] * bb[0] + bb[1] * bb[1] + bb[2] * bb[2];
+    const float s = bX / b2;
+    const float d = a.diameters[c];
+    float gp[3], lsum = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      const float diff = 50.f * (bb[i] * s - X[i]) / d;
+      const float ad = fabsf(diff);
+      lsum += ad < 1.f ? 0.5f * diff * diff : ad - 0.5f;
+      const float dl = ad < 1.f ? diff : (diff > 0.f ? 1.f : -1.f);
+      gp[i] = dl / (24.f * d);     // d(loss_cell)/d(proj_i): (50/d) * (1/24) * (1/50)
+    }
+    acc += lsum / (24.f * 50.f);
+    // proj = b * s ; s = (b.X)/(b.b)
+    const float gpb = gp[0] * bb[0] + gp[1] * bb[1] + gp[2] * bb[2];
+    float gb[3];
+    for (int i = 0; i < 3; ++i) gb[i] = s * gp[i] + gpb * (X[i] / b2 - 2.f * bX * bb[i] / (b2 * b2));
+    a.g_reg_xy[o * 2 + 0] = gb[0] * a.kinv[0] + gb[1] * a.kinv[3] + gb[2] * a.kinv[6];
+    a.g_reg_xy[o * 2 + 1] = gb[0] * a.kinv[1] + gb[1] * a.kinv[4] + gb[2] * a.kinv[7];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kT / 64; ++w) s += s_part[w];
+    atomicAdd(a.loss_reg, s);
+  }
+}
+
+// loss_kd = mean over valid images of loss_img (kd_loss.py:99-103)
+__global__ void kd_mean_kernel(const float* __restrict__ loss_img, const int* __restrict__ valid_img,
+                               int n, float* loss_kd, int* n_valid) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f; int v = 0;
+    for (int i = 0; i < n; ++i)
+      if (valid_img[i] > 0) { s += loss_img[i]; ++v; }
+    *loss_kd = v > 0 ? s / (float)v : 0.f;
+    *n_valid = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Chain d(loss)/d(points, alpha) into the logit-gradient tensors of the positive rows.
+// ------------------------------------------------------------------------------------
+struct BackwardArgs {
+  const float* cls; const float* reg;
+  const int* pos_cnt; const int* pos_row; const int* pos_gt; const int* class_ids;
+  const float* bbox_trans;
+  const float* g_reg_xy; const float* g_kd_xs; const float* g_kd_alpha;
+  const int* n_valid; const int* valid_img;
+  const float* weights;      // {w_cls, w_reg, w_kd} upstream gradients of the three losses
+  const float* seg_scale;    // PoseHead.scales (per level), may be null
+  float* dseg_scale;         // gradient of the scales (fp32, accumulated), may be null
+  float frame_w, frame_h;
+  int cap; int detach_alpha;
+  void* dcls; void* dreg;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kT) void loss_backward_kernel(Levels L, BackwardArgs a) {
+  const int b = blockIdx.x;
+  const int n = a.pos_cnt[b];
+  const float w_reg = a.weights[1];
+  const int nv = a.n_valid[0];
+  const float w_kd = (nv > 0 && a.valid_img[b] > 0) ? a.weights[2] / (float)nv : 0.f;
+  float ai[4];
+  inv2x2(a.bbox_trans + b * 6, ai);
+  T* dcls = reinterpret_cast<T*>(a.dcls);
+  T* dreg = reinterpret_cast<T*>(a.dreg);
+  for (int e = threadIdx.x; e < n * 8; e += kT) {
+    const int slot = e >> 3, k = e & 7;
+    const int row = a.pos_row[b * a.cap + slot];
+    const int g = a.pos_gt[b * a.cap + slot];
+    const int c = a.class_ids[b * kMaxGt + g];
+    int l, cell, w; float st, sz;
+    locate_row(L, row, l, cell, w, st, sz);
+    const size_t o = (size_t)(b * a.cap + slot) * 8 + k;
+    const float gx = w_reg * a.g_reg_xy[o * 2 + 0] + w_kd * a.g_kd_xs[o * 2 + 0] / a.frame_w;
+    const float gy = w_reg * a.g_reg_xy[o * 2 + 1] + w_kd * a.g_kd_xs[o * 2 + 1] / a.frame_h;
+    // [x;y] = Ainv ([px;py] - t)  =>  d/dp = Ainv^T g ; p = pred * size + centre
+    float dpx = (ai[0] * gx + ai[2] * gy) * sz;
+    float dpy = (ai[1] * gx + ai[3] * gy) * sz;
+    float sc = 1.f;
+    if (a.seg_scale) {
+#pragma unroll
+      for (int s = 0; s < KD6D_MAX_SEG; ++s)
+        if (s == l) sc = a.seg_scale[s];
+      if (a.dseg_scale) {
+        const float* r = a.reg + (size_t)row * 240 + c * 16;
+        // d/dscale = sum grad * raw = sum grad * out / scale
+        atomicAdd(a.dseg_scale + l, (dpx * r[k] + dpy * r[8 + k]) / sc);
+      }
+    }
+    dreg[(size_t)row * 240 + c * 16 + k] = from_f32<T>(dpx * sc);
+    dreg[(size_t)row * 240 + c * 16 + 8 + k] = from_f32<T>(dpy * sc);
+  }
+  if (!a.detach_alpha) {
+    for (int slot = threadIdx.x; slot < n; slot += kT) {
+      const int row = a.pos_row[b * a.cap + slot];
+      const int g = a.pos_gt[b * a.cap + slot];
+      const int c = a.class_ids[b * kMaxGt + g];
+      float ga = 0.f;
+      for (int k = 0; k < 8; ++k) ga += a.g_kd_alpha[(size_t)(b * a.cap + slot) * 8 + k];
+      const float p = sigmoidf_(a.cls[(size_t)row * 16 + c]);
+      if (p >= 1e-3f && p <= 1.f - 1e-3f) {
+        const size_t o = (size_t)row * 16 + c;
+        dcls[o] = from_f32<T>(to_f32<T>(dcls[o]) + w_kd * ga * p * (1.f - p));
+      }
+    }
+  }
+}
+
+bool fill_levels(const kd6d_levels* lv, Levels* L) {
+  if (!lv || lv->n < 1 || lv->n > KD6D_MAX_SEG || lv->batch < 1) return false;
+  memset(L, 0, sizeof(*L));
+  L->n = lv->n; L->batch = lv->batch;
+  int row = 0;
+  for (int s = 0; s < KD6D_MAX_SEG; ++s) {
+    L->size[s] = lv->anchor_size[s];
+    L->stride[s] = lv->anchor_stride[s];
+    if (s < lv->n) {
+      if (lv->h[s] <= 0 || lv->w[s] <= 0 || lv->anchor_size[s] <= 0.f || lv->anchor_stride[s] <= 0.f) return false;
+      L->h[s] = lv->h[s]; L->w[s] = lv->w[s]; L->row0[s] = row;
+      row += lv->batch * lv->h[s] * lv->w[s];
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, const float* reg,
+                                   const float* bbox_trans, float threshold, float positive_num,
+                                   float positive_lambda, int cap, float frame_w, float frame_h,
+                                   int32_t* t_cnt, float* t_kp, float* t_score, int32_t* t_row,
+                                   float* t_kp_norm, float* t_beta, void* stream) {
+  Levels L;
+  KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_teacher_select: bad level table");
+  KD6D_CHECK_ARG(cls && reg && bbox_trans && t_cnt && t_kp && t_score && t_row && t_kp_norm && t_beta && cap > 0 &&
+                     frame_w > 0.f && frame_h > 0.f,
+                 "kd6d_teacher_select: bad arguments");
+  KD6D_CHECK_ARG(threshold > 0.f && threshold < 1.f, "kd6d_teacher_select: threshold must be in (0,1)");
+  hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream),
+                     cls, reg, L, bbox_trans, threshold, positive_num, positive_lambda, cap, frame_w, frame_h,
+                     t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta);
+  KD6D_CHECK_LAUNCH("kd6d_teacher_select");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int mask_h, int mask_w,
+                               const float* kp3d, const float* K, const int32_t* class_ids,
+                               const int32_t* n_gt, const float* rot, const float* trans,
+                               const float* bbox_trans, const float* keys, float positive_num,
+                               float positive_lambda, int cap, int32_t* labels, int32_t* pos_cnt,
+                               int32_t* pos_row, int32_t* pos_gt, void* stream) {
+  Levels L;
+  KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_ssc_assign: bad level table");
+  KD6D_CHECK_ARG(mask && kp3d && K && class_ids && n_gt && rot && trans && bbox_trans && keys && labels &&
+                     pos_cnt && pos_row && pos_gt && cap > 0 && cap <= 64 && mask_h > 0 && mask_w > 0,
+                 "kd6d_ssc_assign: bad arguments (cap must be in 1..64)");
+  hipLaunchKernelGGL(ssc_assign_kernel, dim3(L.batch), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), L,
+                     mask, mask_h, mask_w, kp3d, K, class_ids, n_gt, rot, trans, bbox_trans, keys,
+                     positive_num, positive_lambda, cap, labels, pos_cnt, pos_row, pos_gt);
+  KD6D_CHECK_LAUNCH("kd6d_ssc_assign");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_focal_fwd(const float* cls, const int32_t* labels, int rows, float gamma, float alpha,
+                              float* loss, void* stream) {
+  KD6D_CHECK_ARG(cls && labels && loss && rows > 0, "kd6d_focal_fwd: bad arguments");
+  int nb = (rows * 15 + kT - 1) / kT;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(nb), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), cls, labels,
+                     rows, gamma, alpha, loss);
+  KD6D_CHECK_LAUNCH("kd6d_focal_fwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_focal_bwd(int dtype, const float* cls, const int32_t* labels, int rows, float gamma,
+                              float alpha, const float* weight, void* dcls, void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_focal_bwd: bad dtype");
+  KD6D_CHECK_ARG(cls && labels && weight && dcls && rows > 0, "kd6d_focal_bwd: bad arguments");
+  int nb = (rows * 16 + kT - 1) / kT;
+  if (nb > 2048) nb = 2048;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == KD6D_BF16)
+    hipLaunchKernelGGL(focal_bwd_kernel<bf16_t>, dim3(nb), dim3(kT), 0, st, cls, labels, rows, gamma, alpha,
+                       weight, reinterpret_cast<bf16_t*>(dcls));
+  else
+    hipLaunchKernelGGL(focal_bwd_kernel<float>, dim3(nb), dim3(kT), 0, st, cls, labels, rows, gamma, alpha,
+                       weight, reinterpret_cast<float*>(dcls));
+  KD6D_CHECK_LAUNCH("kd6d_focal_bwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_student_points(const kd6d_levels* levels, const float* cls, const float* reg,
+                                   const int32_t* pos_cnt, const int32_t* pos_row, const int32_t* pos_gt,
+                                   const int32_t* class_ids, const float* kp3d, const float* rot,
+                                   const float* trans, const float* bbox_trans, const float* diameters,
+                                   const float* kinv_host, float frame_w, float frame_h, int cap, float* xs,
+                                   float* alpha, float* g_reg_xy, float* loss_reg, int32_t* s_start,
+                                   void* stream) {
+  Levels L;
+  KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_student_points: bad level table");
+  KD6D_CHECK_ARG(cls && reg && pos_cnt && pos_row && pos_gt && class_ids && kp3d && rot && trans &&
+                     bbox_trans && diameters && kinv_host && xs && alpha && g_reg_xy && loss_reg && s_start,
+                 "kd6d_student_points: null pointer");
+  StudentArgs a;
+  a.cls = cls; a.reg = reg; a.pos_cnt = pos_cnt; a.pos_row = pos_row; a.pos_gt = pos_gt;
+  a.class_ids = class_ids; a.kp3d = kp3d; a.rot = rot; a.trans = trans; a.bbox_trans = bbox_trans;
+  a.diameters = diameters;
+  for (int i = 0; i < 9; ++i) a.kinv[i] = kinv_host[i];
+  a.frame_w = frame_w; a.frame_h = frame_h; a.cap = cap;
+  a.xs = xs; a.alpha = alpha; a.g_reg_xy = g_reg_xy; a.loss_reg = loss_reg; a.s_start = s_start;
+  hipLaunchKernelGGL(student_points_kernel, dim3(L.batch), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), L, a);
+  KD6D_CHECK_LAUNCH("kd6d_student_points");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_kd_mean(const float* loss_img, const int32_t* valid_img, int n_images, float* loss_kd,
+                            int32_t* n_valid, void* stream) {
+  KD6D_CHECK_ARG(loss_img && valid_img && loss_kd && n_valid && n_images > 0, "kd6d_kd_mean: bad arguments");
+  hipLaunchKernelGGL(kd_mean_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), loss_img,
+                     valid_img, n_images, loss_kd, n_valid);
+  KD6D_CHECK_LAUNCH("kd6d_kd_mean");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const float* cls, const float* reg,
+                                  const int32_t* pos_cnt, const int32_t* pos_row, const int32_t* pos_gt,
+                                  const int32_t* class_ids, const float* bbox_trans, const float* g_reg_xy,
+                                  const float* g_kd_xs, const float* g_kd_alpha, const int32_t* n_valid,
+                                  const int32_t* valid_img, const float* weights, const float* seg_scale,
+                                  float* dseg_scale, float frame_w, float frame_h, int cap, int detach_alpha,
+                                  void* dcls, void* dreg, void* stream) {
+  Levels L;
+  KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_loss_backward: bad level table");
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_loss_backward: bad dtype");
+  KD6D_CHECK_ARG(cls && reg && pos_cnt && pos_row && pos_gt && class_ids && bbox_trans && g_reg_xy && g_kd_xs &&
+                     g_kd_alpha && n_valid && valid_img && weights && dcls && dreg,
+                 "kd6d_loss_backward: null pointer");
+  BackwardArgs a;
+  a.cls = cls; a.reg = reg; a.pos_cnt = pos_cnt; a.pos_row = pos_row; a.pos_gt = pos_gt; a.class_ids = class_ids;
+  a.bbox_trans = bbox_trans; a.g_reg_xy = g_reg_xy; a.g_kd_xs = g_kd_xs; a.g_kd_alpha = g_kd_alpha;
+  a.n_valid = n_valid; a.valid_img = valid_img; a.weights = weights; a.seg_scale = seg_scale;
+  a.dseg_scale = dseg_scale; a.frame_w = frame_w; a.frame_h = frame_h; a.cap = cap;
+  a.detach_alpha = detach_alpha; a.dcls = dcls; a.dreg = dreg;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == KD6D_BF16) hipLaunchKernelGGL(loss_backward_kernel<bf16_t>, dim3(L.batch), dim3(kT), 0, st, L, a);
+  else hipLaunchKernelGGL(loss_backward_kernel<float>, dim3(L.batch), dim3(kT), 0, st, L, a);
+  KD6D_CHECK_LAUNCH("kd6d_loss_backward");
+  return KD6D_OK;
+}

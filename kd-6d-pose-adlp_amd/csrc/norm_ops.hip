@@ -34,31 +34,55 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
   }
 }
 
+// Row-tiled variant of the ownership rule: thread t owns channel granule t % cgs of row t / cgs
+// (threads beyond (256/cgs)*cgs idle), so any C with C/EG <= 256 works (e.g. C = 240 bias grads).
 template <typename T>
-__global__ __launch_bounds__(kThreads) void colstats_kernel(const T* __restrict__ x, long long ngran,
+__global__ __launch_bounds__(kThreads) void colstats_kernel(const T* __restrict__ x, long long rows,
                                                             int C, float* sum, float* sumsq) {
   constexpr int EG = Granule<T>::N;
   const int cgs = C / EG;
+  const int rpp = kThreads / cgs;            // rows per pass
   const int cg = threadIdx.x % cgs;
+  const int rsub = threadIdx.x / cgs;
   float acc[2][EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
   const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
-  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
-       g += (long long)gridDim.x * kThreads) {
-    float v[EG];
-    granule_to_f32<T>(xg[g], v);
+  if (rsub < rpp) {
+    for (long long r = (long long)blockIdx.x * rpp + rsub; r < rows; r += (long long)gridDim.x * rpp) {
+      float v[EG];
+      granule_to_f32<T>(xg[r * cgs + cg], v);
 #pragma unroll
-    for (int e = 0; e < EG; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+      for (int e = 0; e < EG; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+    }
   }
   float* outs[2] = {sum, sumsq};
   block_channel_flush<2, EG>(acc, C, cg, outs);
 }
 
+// Granule g (EG consecutive channels) of a tensor stored as TX; TX = float with EG = 8 is the
+// "fp32 pre-normalisation tensor, bf16 activations" case: the conv output that feeds BN / GN is
+// kept in fp32 so that (x - mean) does not cancel bf16 rounding error.
+template <typename TX, int EG>
+__device__ __forceinline__ void load_x(const TX* __restrict__ base, long long g, float* v);
+template <>
+__device__ __forceinline__ void load_x<bf16_t, 8>(const bf16_t* __restrict__ base, long long g, float* v) {
+  granule_to_f32<bf16_t>(reinterpret_cast<const u32x4_t*>(base)[g], v);
+}
+template <>
+__device__ __forceinline__ void load_x<float, 4>(const float* __restrict__ base, long long g, float* v) {
+  granule_to_f32<float>(reinterpret_cast<const u32x4_t*>(base)[g], v);
+}
+template <>
+__device__ __forceinline__ void load_x<float, 8>(const float* __restrict__ base, long long g, float* v) {
+  granule_to_f32<float>(reinterpret_cast<const u32x4_t*>(base)[2 * g], v);
+  granule_to_f32<float>(reinterpret_cast<const u32x4_t*>(base)[2 * g + 1], v + 4);
+}
+
 // y = act(gamma * (x - mean) * invstd + beta), mean/var from the batch sums.
-template <typename T>
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
-    const T* __restrict__ x, T* __restrict__ y, long long ngran, int C, float inv_rows,
+    const TX* __restrict__ x, T* __restrict__ y, long long ngran, int C, float inv_rows,
     const float* __restrict__ sum, const float* __restrict__ sumsq, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float unbias,
     float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act) {
@@ -86,12 +110,11 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
       if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
     }
   }
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float v[EG];
-    granule_to_f32<T>(xg[g], v);
+    load_x<TX, EG>(x, g, v);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
       float t = v[e] * sc[e] + sh[e];
@@ -104,9 +127,9 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
 }
 
 // reduce pass of BN backward: sum(dy), sum(dy * xhat) per channel, dy = dz * act'(bn(x))
-template <typename T>
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
-    const T* __restrict__ x, const T* __restrict__ dz, long long ngran, int C,
+    const TX* __restrict__ x, const T* __restrict__ dz, long long ngran, int C,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy,
     float* sum_dy_xhat) {
@@ -122,12 +145,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
   float acc[2][EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float xv[EG], dv[EG];
-    granule_to_f32<T>(xg[g], xv);
+    load_x<TX, EG>(x, g, xv);
     granule_to_f32<T>(dg[g], dv);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
@@ -144,9 +166,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
   block_channel_flush<2, EG>(acc, C, cg, outs);
 }
 
-template <typename T>
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
-    const T* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int C,
+    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int C,
     float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* dgamma,
@@ -168,13 +190,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
       if (dbeta) dbeta[c] += sum_dy[c];
     }
   }
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
   u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float xv[EG], dv[EG];
-    granule_to_f32<T>(xg[g], xv);
+    load_x<TX, EG>(x, g, xv);
     granule_to_f32<T>(dg[g], dv);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
@@ -200,8 +221,8 @@ struct GnGeom {
 };
 
 // stats[(seg*batch + b)*G + g] = {mean, rstd}
-template <typename T>
-__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict__ x, GnGeom gm,
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict__ x, GnGeom gm,
                                                             float eps, float* __restrict__ stats) {
   constexpr int EG = Granule<T>::N;
   __shared__ float s_sum[64], s_sq[64];
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
   __syncthreads();
   const int cgs = C / EG;
   const long long ngran = (long long)hw * cgs;
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x + (size_t)(row0 + b * hw) * C);
+  const TX* xb = x + (size_t)(row0 + b * hw) * C;
   const int cg = threadIdx.x % cgs;  // (C/EG) | 256
   // a granule may straddle groups when cpg < EG (C=128,G=32,bf16: 2 groups per granule)
   float a1[EG], a2[EG];
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
   for (int e = 0; e < EG; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
   for (long long g = threadIdx.x; g < ngran; g += kThreads) {
     float v[EG];
-    granule_to_f32<T>(xg[g], v);
+    load_x<TX, EG>(xb, g, v);
 #pragma unroll
     for (int e = 0; e < EG; ++e) { a1[e] += v[e]; a2[e] += v[e] * v[e]; }
   }
@@ -253,9 +274,9 @@ __device__ __forceinline__ void gn_locate(const GnGeom& gm, long long row, int& 
   b = (int)((row - r0) / hw);
 }
 
-template <typename T>
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
-    const T* __restrict__ x, T* __restrict__ y, GnGeom gm, long long ngran,
+    const TX* __restrict__ x, T* __restrict__ y, GnGeom gm, long long ngran,
     const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta) {
   constexpr int EG = Granule<T>::N;
@@ -264,7 +285,6 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
   float ga[EG], be[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
     gn_locate(gm, row, seg, b);
     const float* st = stats + ((size_t)(seg * gm.batch + b) * G) * 2;
     float v[EG];
-    granule_to_f32<T>(xg[g], v);
+    load_x<TX, EG>(x, g, v);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
       const int grp = (cg * EG + e) / cpg;
@@ -286,9 +306,9 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
 
 // backward reduce: one workgroup per (level, sample):
 //   gsum[(seg,b,g)] = {sum(dy*gamma), sum(dy*gamma*xhat)}; dgamma/dbeta via atomics.
-template <typename T>
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
-    const T* __restrict__ x, const T* __restrict__ dz, GnGeom gm, const float* __restrict__ stats,
+    const TX* __restrict__ x, const T* __restrict__ dz, GnGeom gm, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gsum,
     float* dgamma, float* dbeta) {
   constexpr int EG = Granule<T>::N;
@@ -316,12 +336,12 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
 #pragma unroll
   for (int e = 0; e < EG; ++e) { a_dy[e] = 0.f; a_dyx[e] = 0.f; }
   const size_t base = (size_t)(row0 + b * hw) * C;
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x + base);
+  const TX* xb = x + base;
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz + base);
   const long long ngran = (long long)hw * cgs;
   for (long long g = threadIdx.x; g < ngran; g += kThreads) {
     float xv[EG], dv[EG];
-    granule_to_f32<T>(xg[g], xv);
+    load_x<TX, EG>(xb, g, xv);
     granule_to_f32<T>(dg[g], dv);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
@@ -352,9 +372,9 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
   }
 }
 
-template <typename T>
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
-    const T* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm,
+    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm,
     long long ngran, const float* __restrict__ stats, const float* __restrict__ gsum,
     const float* __restrict__ gamma, const float* __restrict__ beta) {
   constexpr int EG = Granule<T>::N;
@@ -363,7 +383,6 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
   float ga[EG], be[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
-  const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
   u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
@@ -378,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
     const float inv_n = 1.f / ((float)hw * (float)cpg);
     const size_t sb = (size_t)(seg * gm.batch + b) * G;
     float xv[EG], dv[EG];
-    granule_to_f32<T>(xg[g], xv);
+    load_x<TX, EG>(x, g, xv);
     granule_to_f32<T>(dg[g], dv);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
@@ -620,26 +639,34 @@ long long gn_rows(const GnGeom& gm) {
 
 extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum,
                              float* sumsq, void* stream) {
-  int rc = check_channels(dtype, C, "kd6d_colstats");
-  if (rc) return rc;
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_colstats: bad dtype %d", dtype);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(C > 0 && C % eg == 0 && C / eg <= kThreads, "kd6d_colstats: C=%d must be a multiple of %d and <= %d",
+                 C, eg, eg * kThreads);
   KD6D_CHECK_ARG(x && rows > 0, "kd6d_colstats: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int eg = dtype == KD6D_BF16 ? 8 : 4;
-  const long long ngran = rows * (C / eg);
-  long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
+  const int rpp = kThreads / (C / eg);
+  long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((int)nb), dim3(kThreads), lds, st,
-                                (const bf16_t*)x, ngran, C, sum, sumsq),
+                                (const bf16_t*)x, (long long)rows, C, sum, sumsq),
              hipLaunchKernelGGL(colstats_kernel<float>, dim3((int)nb), dim3(kThreads), lds, st,
-                                (const float*)x, ngran, C, sum, sumsq));
+                                (const float*)x, (long long)rows, C, sum, sumsq));
   KD6D_CHECK_LAUNCH("kd6d_colstats");
   return KD6D_OK;
 }
 
-extern "C" int kd6d_bn_train_fwd(int dtype, const void* x, void* y, int64_t rows, int C,
+#define DISPATCH_TTX(dtype, xf32, CALL)                                        \
+  do {                                                                         \
+    if ((dtype) == KD6D_F32) { typedef float T_; typedef float TX_; CALL; }     \
+    else if (xf32) { typedef bf16_t T_; typedef float TX_; CALL; }              \
+    else { typedef bf16_t T_; typedef bf16_t TX_; CALL; }                       \
+  } while (0)
+
+extern "C" int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows, int C,
                                  const float* sum, const float* sumsq, const float* gamma,
                                  const float* beta, float eps, float momentum, float* running_mean,
                                  float* running_var, float* save_mean, float* save_invstd, int act,
@@ -653,23 +680,18 @@ extern "C" int kd6d_bn_train_fwd(int dtype, const void* x, void* y, int64_t rows
   const float inv_rows = 1.f / (float)rows;
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
   const int nb = grid_for((ngran + 3) / 4);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
-                                (const bf16_t*)x, (bf16_t*)y, ngran, C, inv_rows, sum, sumsq, gamma,
-                                beta, eps, momentum, unbias, running_mean, running_var, save_mean,
-                                save_invstd, act),
-             hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
-                                (const float*)x, (float*)y, ngran, C, inv_rows, sum, sumsq, gamma,
-                                beta, eps, momentum, unbias, running_mean, running_var, save_mean,
-                                save_invstd, act));
+  DISPATCH_TTX(dtype, x_f32,
+               hipLaunchKernelGGL((bn_apply_fwd_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st,
+                                   (const TX_*)x, (T_*)y, ngran, C, inv_rows, sum, sumsq, gamma, beta, eps,
+                                   momentum, unbias, running_mean, running_var, save_mean, save_invstd, act));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_fwd");
   return KD6D_OK;
 }
 
-extern "C" int kd6d_bn_train_bwd_reduce(int dtype, const void* x, const void* dz, int64_t rows, int C,
-                                        const float* mean, const float* invstd, const float* gamma,
-                                        const float* beta, int act, float* sum_dy,
-                                        float* sum_dy_xhat, void* stream) {
+extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, const void* dz, int64_t rows,
+                                        int C, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, int act, float* sum_dy, float* sum_dy_xhat,
+                                        void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_reduce");
   if (rc) return rc;
   KD6D_CHECK_ARG(x && dz && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
@@ -681,18 +703,15 @@ extern "C" int kd6d_bn_train_bwd_reduce(int dtype, const void* x, const void* dz
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)nb), dim3(kThreads), lds, st,
-                                (const bf16_t*)x, (const bf16_t*)dz, ngran, C, mean, invstd, gamma,
-                                beta, act, sum_dy, sum_dy_xhat),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)nb), dim3(kThreads), lds, st,
-                                (const float*)x, (const float*)dz, ngran, C, mean, invstd, gamma,
-                                beta, act, sum_dy, sum_dy_xhat));
+  DISPATCH_TTX(dtype, x_f32,
+               hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads), lds, st,
+                                   (const TX_*)x, (const T_*)dz, ngran, C, mean, invstd, gamma, beta, act, sum_dy,
+                                   sum_dy_xhat));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_reduce");
   return KD6D_OK;
 }
 
-extern "C" int kd6d_bn_train_bwd_apply(int dtype, const void* x, const void* dz, void* dx,
+extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz, void* dx,
                                        int64_t rows, int C, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, int act,
                                        const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
@@ -706,18 +725,15 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, const void* x, const void* dz,
   const long long ngran = rows * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
   const float inv_rows = 1.f / (float)rows;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
-                                (const bf16_t*)x, (const bf16_t*)dz, (bf16_t*)dx, ngran, C, inv_rows,
-                                mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta),
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
-                                (const float*)x, (const float*)dz, (float*)dx, ngran, C, inv_rows,
-                                mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta));
+  DISPATCH_TTX(dtype, x_f32,
+               hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st,
+                                   (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, C, inv_rows, mean, invstd, gamma,
+                                   beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_apply");
   return KD6D_OK;
 }
 
-extern "C" int kd6d_gn_relu_fwd(int dtype, const void* x, void* y, const int32_t* level_hw_host,
+extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host,
                                 int nseg, int batch, int C, int groups, const float* gamma,
                                 const float* beta, float eps, float* stats, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_gn_relu_fwd");
@@ -730,20 +746,17 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, const void* x, void* y, const int32_t
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
-  DISPATCH_T(dtype,
-             { hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nseg * batch), dim3(kThreads), 0, st,
-                                  (const bf16_t*)x, gm, eps, stats);
-               hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
-                                  (const bf16_t*)x, (bf16_t*)y, gm, ngran, stats, gamma, beta); },
-             { hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nseg * batch), dim3(kThreads), 0, st,
-                                  (const float*)x, gm, eps, stats);
-               hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
-                                  (const float*)x, (float*)y, gm, ngran, stats, gamma, beta); });
+  DISPATCH_TTX(dtype, x_f32, {
+    hipLaunchKernelGGL((gn_stats_kernel<T_, TX_>), dim3(nseg * batch), dim3(kThreads), 0, st, (const TX_*)x, gm,
+                       eps, stats);
+    hipLaunchKernelGGL((gn_relu_fwd_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x, (T_*)y, gm,
+                       ngran, stats, gamma, beta);
+  });
   KD6D_CHECK_LAUNCH("kd6d_gn_relu_fwd");
   return KD6D_OK;
 }
 
-extern "C" int kd6d_gn_relu_bwd(int dtype, const void* x, const void* dz, void* dx,
+extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx,
                                 const int32_t* level_hw_host, int nseg, int batch, int C, int groups,
                                 const float* gamma, const float* beta, const float* stats,
                                 float* gsum_ws, float* dgamma, float* dbeta, void* stream) {
@@ -758,19 +771,12 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, const void* x, const void* dz, void* 
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
   const size_t lds = (size_t)2 * C * sizeof(float);
-  DISPATCH_T(dtype,
-             { hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<bf16_t>, dim3(nseg * batch), dim3(kThreads),
-                                  lds, st, (const bf16_t*)x, (const bf16_t*)dz, gm, stats, gamma, beta,
-                                  gsum_ws, dgamma, dbeta);
-               hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, st,
-                                  (const bf16_t*)x, (const bf16_t*)dz, (bf16_t*)dx, gm, ngran, stats,
-                                  gsum_ws, gamma, beta); },
-             { hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<float>, dim3(nseg * batch), dim3(kThreads),
-                                  lds, st, (const float*)x, (const float*)dz, gm, stats, gamma, beta,
-                                  gsum_ws, dgamma, dbeta);
-               hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
-                                  (const float*)x, (const float*)dz, (float*)dx, gm, ngran, stats,
-                                  gsum_ws, gamma, beta); });
+  DISPATCH_TTX(dtype, x_f32, {
+    hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<T_, TX_>), dim3(nseg * batch), dim3(kThreads), lds, st,
+                       (const TX_*)x, (const T_*)dz, gm, stats, gamma, beta, gsum_ws, dgamma, dbeta);
+    hipLaunchKernelGGL((gn_relu_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x,
+                       (const T_*)dz, (T_*)dx, gm, ngran, stats, gsum_ws, gamma, beta);
+  });
   KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd");
   return KD6D_OK;
 }

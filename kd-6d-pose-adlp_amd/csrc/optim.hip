@@ -1,0 +1,105 @@
+// Fused optimiser side of the KD step over ONE flat fp32 parameter/gradient buffer.
+//
+// Replaces train_kd.py:138-139: nn.utils.clip_grad_norm_(model.parameters(), 1.0) followed by
+// torch.optim.AdamW(lr, weight_decay=1e-4, eps=1e-8).step() (libs/train_libs.py:119): the
+// reference walks 150 tensors with several launches each; here it is two launches
+// (sum of squares, then clip + AdamW + optional bf16 shadow refresh), HBM-bound:
+// 16 B read + 12 B (+2 B) written per parameter.
+#include "kd6d_common.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+__global__ __launch_bounds__(kT) void sumsq_kernel(const float* __restrict__ x, long long n,
+                                                   float* __restrict__ out) {
+  __shared__ float s_part[kT / 64];
+  float acc = 0.f;
+  const long long n4 = n >> 2;
+  const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(x);
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n4; i += (long long)gridDim.x * kT) {
+    const f32x4_t v = x4[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += kT) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kT / 64; ++w) s += s_part[w];
+    atomicAdd(out, s);
+  }
+}
+
+__global__ __launch_bounds__(kT) void clip_adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        long long n, const float* __restrict__ gnorm_sq,
+                                                        float max_norm, float lr, float beta1, float beta2,
+                                                        float eps, float wd, float bc1, float bc2_sqrt,
+                                                        bf16_t* __restrict__ shadow) {
+  float coef = 1.f;
+  if (gnorm_sq && max_norm > 0.f) {
+    const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);
+    coef = c < 1.f ? c : 1.f;
+  }
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * mi / denom;
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = (bf16_t)pi;
+  }
+}
+
+__global__ __launch_bounds__(kT) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                       long long n) {
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT)
+    y[i] = (bf16_t)x[i];
+}
+
+int blocks_for(long long n) {
+  long long b = (n + kT * 4 - 1) / (kT * 4);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int kd6d_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  KD6D_CHECK_ARG(x && out && n > 0, "kd6d_sumsq: bad arguments");
+  KD6D_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "kd6d_sumsq: x must be 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n)), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     (long long)n, out);
+  KD6D_CHECK_LAUNCH("kd6d_sumsq");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               const float* gnorm_sq, double max_norm, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, int64_t step, void* bf16_shadow, void* stream) {
+  KD6D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "kd6d_clip_adamw: bad arguments");
+  // bias corrections in double, like torch's python-float arithmetic
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(clip_adamw_kernel, dim3(blocks_for(n)), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream),
+                     param, grad, exp_avg, exp_avg_sq, (long long)n, gnorm_sq, (float)max_norm, (float)lr,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1, bc2_sqrt,
+                     reinterpret_cast<bf16_t*>(bf16_shadow));
+  KD6D_CHECK_LAUNCH("kd6d_clip_adamw");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  KD6D_CHECK_ARG(x && y && n > 0, "kd6d_cast_f32_to_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for(n)), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<bf16_t*>(y), (long long)n);
+  KD6D_CHECK_LAUNCH("kd6d_cast_f32_to_bf16");
+  return KD6D_OK;
+}

@@ -55,8 +55,9 @@ __device__ __forceinline__ float lse_row(float rx, float ry, const float* cx, co
 }
 
 __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
-    const float* __restrict__ xs, const float* __restrict__ alpha, const int* __restrict__ s_off,
-    const float* __restrict__ yt, const float* __restrict__ beta, const int* __restrict__ t_off,
+    const float* __restrict__ xs, const float* __restrict__ alpha, const int* __restrict__ s_start,
+    const int* __restrict__ s_cnt, const float* __restrict__ yt, const float* __restrict__ beta,
+    const int* __restrict__ t_start, const int* __restrict__ t_cnt,
     float blur, float scaling, float reach, float* __restrict__ loss_img, int* __restrict__ valid_img,
     float* __restrict__ gx_out, float* __restrict__ galpha_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int s0 = s_off[b], N = s_off[b + 1] - s0;
-  const int t0 = t_off[b], M = t_off[b + 1] - t0;
+  const int s0 = s_start[b], N = s_cnt[b];
+  const int t0 = t_start[b], M = t_cnt[b];
   if (N <= 0 || M <= 0) {          // reference: image skipped (loss_libs.py:25-28)
     if (threadIdx.x == 0) { loss_img[b] = 0.f; valid_img[b] = 0; }
     return;
@@ -239,12 +240,12 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
 
 }  // namespace
 
-extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, const int32_t* s_off,
-                                         const float* yt, const float* beta, const int32_t* t_off,
-                                         int n_images, float p, float blur, float scaling,
+extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, const int32_t* s_start,
+                                         const int32_t* s_cnt, const float* yt, const float* beta,
+                                         const int32_t* t_start, const int32_t* t_cnt, int n_images, float p, float blur, float scaling,
                                          float reach, float* loss_img, int32_t* valid_img,
                                          float* grad_xs, float* grad_alpha, void* stream) {
-  KD6D_CHECK_ARG(xs && alpha && s_off && yt && beta && t_off && loss_img && valid_img && grad_xs &&
+  KD6D_CHECK_ARG(xs && alpha && s_start && s_cnt && yt && beta && t_start && t_cnt && loss_img && valid_img && grad_xs &&
                      grad_alpha,
                  "kd6d_sinkhorn_div_fwd_bwd: null pointer");
   KD6D_CHECK_ARG(n_images > 0, "kd6d_sinkhorn_div_fwd_bwd: n_images=%d", n_images);
@@ -263,7 +264,7 @@ extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, co
     attr_set = true;
   }
   hipLaunchKernelGGL(sinkhorn_small_kernel, dim3(n_images), dim3(64 * kWaves), lds, st, xs, alpha,
-                     s_off, yt, beta, t_off, blur, scaling, reach, loss_img, valid_img, grad_xs,
+                     s_start, s_cnt, yt, beta, t_start, t_cnt, blur, scaling, reach, loss_img, valid_img, grad_xs,
                      grad_alpha);
   KD6D_CHECK_LAUNCH("kd6d_sinkhorn_div_fwd_bwd");
   return KD6D_OK;

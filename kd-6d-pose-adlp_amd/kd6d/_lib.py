@@ -31,11 +31,21 @@ class ConvGeom(ctypes.Structure):
                 ("seg", Seg * MAX_SEG)]
 
 
+class Levels(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("batch", ctypes.c_int32),
+                ("h", ctypes.c_int32 * MAX_SEG), ("w", ctypes.c_int32 * MAX_SEG),
+                ("anchor_stride", ctypes.c_float * MAX_SEG), ("anchor_size", ctypes.c_float * MAX_SEG)]
+
+
+MAX_GT = 4
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _I64 = ctypes.c_int64
 _F = ctypes.c_float
 _G = ctypes.POINTER(ConvGeom)
+_L = ctypes.POINTER(Levels)
+_D = ctypes.c_double
 
 # name -> argtypes (every function returns int unless listed in _RESTYPE)
 SIGNATURES = {
@@ -46,11 +56,11 @@ SIGNATURES = {
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P],
     "kd6d_pack_dgrad_weights": [_I, _P, _P, _P, _I, _I, _P],
     "kd6d_colstats": [_I, _P, _I64, _I, _P, _P, _P],
-    "kd6d_bn_train_fwd": [_I, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
-    "kd6d_bn_train_bwd_reduce": [_I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P],
-    "kd6d_bn_train_bwd_apply": [_I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
-    "kd6d_gn_relu_fwd": [_I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _P],
-    "kd6d_gn_relu_bwd": [_I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _P,
+    "kd6d_bn_train_fwd": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
+    "kd6d_bn_train_bwd_reduce": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "kd6d_bn_train_bwd_apply": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _P],
+    "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _P,
                          _P, _P, _P, _P],
     "kd6d_maxpool2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
     "kd6d_maxpool2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -58,8 +68,20 @@ SIGNATURES = {
     "kd6d_sumpool2": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
     "kd6d_eltwise": [_I, _I, _P, _P, _P, _I64, _P],
     "kd6d_image_to_nhwc": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
-    "kd6d_sinkhorn_div_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P],
+    "kd6d_sinkhorn_div_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P],
     "kd6d_sinkhorn_max_points": [],
+    "kd6d_teacher_select": [_L, _P, _P, _P, _F, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "kd6d_ssc_assign": [_L, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
+    "kd6d_focal_fwd": [_P, _P, _I, _F, _F, _P, _P],
+    "kd6d_focal_bwd": [_I, _P, _P, _I, _F, _F, _P, _P, _P],
+    "kd6d_student_points": [_L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_float),
+                            _F, _F, _I, _P, _P, _P, _P, _P, _P],
+    "kd6d_kd_mean": [_P, _P, _I, _P, _P, _P],
+    "kd6d_loss_backward": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I,
+                           _P, _P, _P],
+    "kd6d_sumsq": [_P, _I64, _P, _P],
+    "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P],
+    "kd6d_cast_f32_to_bf16": [_P, _P, _I64, _P],
 }
 _RESTYPE = {"kd6d_last_error": ctypes.c_char_p}
 

@@ -1,0 +1,102 @@
+"""Command line + yaml -> (cfg, cfg_t): the flag surface of arguments/argument_kd.py:15-106.
+
+Every reference flag keeps its name, type and default.  Additive flags of this build:
+--precision {bf16,fp32}, --synthetic, --skip_teacher_eval, --batch_size (per-step GLOBAL batch,
+overrides SOLVER.IMS_PER_BATCH), --image_size.
+"""
+import argparse
+import copy
+
+import yaml
+
+from .argument import custom_cfg
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    s = v.lower()
+    if s in ("yes", "true", "t", "y", "1"):
+        return True
+    if s in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def get_argparser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--local_rank", type=int, default=0)
+    p.add_argument("--config_file", type=str, default="./configs/ape.yaml")
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--working_dir", type=str, default="./outputs/")
+    p.add_argument("--test_file", type=str, default="")
+    p.add_argument("--weight_file", type=str, default="")
+    p.add_argument("--running_device", type=str, default="cuda")
+    p.add_argument("--backbone", type=str, default="darknet_tiny_h")
+    p.add_argument("--max_iters", type=int, default=20000, help="max iteration")
+    p.add_argument("--base_lr", type=float, default=0.001, help="base learning rate")
+    # teacher
+    p.add_argument("--config_file_t", type=str, default="./configs/occ_linemod.yaml")
+    p.add_argument("--backbone_t", type=str, default="darknet53")
+    p.add_argument("--weight_file_t", type=str, default="")
+    # distillation
+    p.add_argument("--kd_weight", type=float, default=5, help="weight of loss_kd_loss")
+    p.add_argument("--kd_level", type=str, default="pred", help="level to be distilled")
+    p.add_argument("--gtype", type=str, default="sinkhorn", help="function of kd loss",
+                   choices=["l1", "l2", "sinkhorn", "gaussian", "laplacian", "energy"])
+    p.add_argument("--glevel", type=str, default="point", help="level of kd loss", choices=["point"])
+    p.add_argument("--p", type=float, default=2.0, help="p of loss_kd_loss")
+    p.add_argument("--blur", type=float, default=0.001, help="blur of loss_kd_loss")
+    p.add_argument("--gnD", type=int, default=2, help="dimensions of loss_kd_loss")
+    p.add_argument("--weightedOT", type=str2bool, nargs="?", const=True, default=True, help="weighted OT of loss_kd_loss")
+    p.add_argument("--wot_detach", type=str2bool, nargs="?", const=True, default=False, help="weighted ot with detached cls")
+    p.add_argument("--scaling", type=float, default=0.5, help="param for sinkhorn loss")
+    p.add_argument("--reach", type=float, default=0.5, help="param for sinkhorn loss")
+    # additive (this build)
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--synthetic", action="store_true", help="seeded LINEMOD-shaped synthetic batches (no dataset)")
+    p.add_argument("--skip_teacher_eval", action="store_true")
+    p.add_argument("--batch_size", type=int, default=0, help="global batch; 0 = SOLVER.IMS_PER_BATCH")
+    p.add_argument("--image_size", type=int, default=256, help="synthetic crop size")
+    return p
+
+
+def _runtime(args, config_file, weight_file):
+    return dict(LOCAL_RANK=args.local_rank, CONFIG_FILE=config_file, NUM_WORKERS=args.num_workers,
+                WEIGHT_FILE=weight_file, RUNNING_DEVICE=args.running_device, PRECISION=args.precision)
+
+
+def build_cfgs(args):
+    with open(args.config_file, "r") as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    cfg["RUNTIME"] = _runtime(args, args.config_file, args.weight_file)
+    cfg["RUNTIME"]["WORKING_DIR"] = args.working_dir
+    cfg["RUNTIME"]["SYNTHETIC"] = bool(args.synthetic)
+    cfg["RUNTIME"]["SKIP_TEACHER_EVAL"] = bool(args.skip_teacher_eval)
+    cfg["RUNTIME"]["IMAGE_SIZE"] = int(args.image_size)
+    if len(args.test_file) > 0:
+        cfg["DATASETS"]["TEST"] = args.test_file
+    cfg["MODEL"]["BACKBONE"] = args.backbone
+    cfg = custom_cfg(cfg)
+    cfg["SOLVER"]["MAX_ITER"] = args.max_iters
+    cfg["SOLVER"]["BASE_LR"] = args.base_lr
+    if args.batch_size > 0:
+        cfg["SOLVER"]["IMS_PER_BATCH"] = args.batch_size
+    cfg.setdefault("KD", {})
+    cfg["KD"]["LOSS_WEIGHT_KD"] = args.kd_weight
+    cfg["KD"]["LEVEL"] = args.kd_level
+    if cfg["KD"]["LEVEL"] == "pred":
+        cfg["KD"].update(GLEVEL=args.glevel, GTYPE=args.gtype, GP=args.p, GBLUR=args.blur, GnD=args.gnD,
+                         WEIGHTED_OT=args.weightedOT, DETACH=args.wot_detach, SCALING=args.scaling, REACH=args.reach)
+    with open(args.config_file_t, "r") as f:
+        cfg_t = yaml.load(f, Loader=yaml.FullLoader)
+    cfg_t["RUNTIME"] = _runtime(args, args.config_file_t, args.weight_file_t)
+    cfg_t["MODEL"]["BACKBONE"] = args.backbone_t
+    cfg_t = custom_cfg(cfg_t)
+    cfg_t.setdefault("KD", {})
+    return cfg, cfg_t
+
+
+def get_args(argv=None):
+    args = get_argparser().parse_args(argv)
+    return build_cfgs(args)

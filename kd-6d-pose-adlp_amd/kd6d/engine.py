@@ -1,0 +1,635 @@
+"""Static executor of the pose network on the kd6d C ABI.
+
+One `PoseNet` = backbone (darknet53 | darknet_tiny | darknet_tiny_h) + FPN + PoseHead laid out
+for MI355X: packed NHWC activations, the head run over ALL pyramid levels in one launch per layer,
+parameters / gradients / Adam state in single flat fp32 buffers (one fused optimiser launch, one
+RCCL all-reduce bucket), a bf16 shadow of the parameters for the bf16 MFMA path, and a hand-written
+reverse sweep instead of an autograd tape (the graph is static).
+
+Reference being replaced: models/model.py:455-487 (PoseModule.__init__), backbone/darknet*.py,
+models/model.py:40-103 (FPN), :370-451 (PoseHead).  Parameter NAMES and logical shapes follow the
+reference state_dict; storage is KRSC with channels padded to multiples of 8.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU
+
+ANCHOR_SIZES = [32, 64, 128, 256, 512]
+ANCHOR_STRIDES = [8, 16, 32, 64, 128]
+TINY_CHANNELS = {
+    "darknet_tiny": [[16], [32], [16, 128, 16, 128], [32, 256, 32, 256], [64, 512, 64, 512, 128]],
+    "darknet_tiny_h": [[8], [16], [8, 64, 8, 64], [16, 128, 16, 128], [32, 256, 32, 256, 64]],
+}
+BACKBONE_CFG = {  # arguments/argument.py:59-68
+    "darknet53": ([0, 0, 256, 512, 1024], 256),
+    "darknet_tiny": ([0, 0, 128, 128], 256),
+    "darknet_tiny_h": ([0, 0, 64, 64], 128),
+}
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------------------
+# flat parameter store
+# ----------------------------------------------------------------------------------------
+class Entry:
+    __slots__ = ("name", "kind", "shape", "store_shape", "offset", "numel", "trainable", "region")
+
+    def __init__(self, name, kind, shape, store_shape, trainable):
+        self.name, self.kind, self.shape, self.store_shape = name, kind, tuple(shape), tuple(store_shape)
+        self.numel = int(math.prod(store_shape))
+        self.trainable = trainable
+        self.offset = -1
+        self.region = None
+
+
+class ParamStore:
+    """Flat fp32 buffers.  Regions: 'train' (optimised), 'frozen' (registered-but-unused parameters
+    such as backbone.output.* and head.scales.4 of a 4-level student: the reference never gives them
+    a gradient, so AdamW never touches them), 'buf' (BN running stats)."""
+
+    ALIGN = 8
+
+    def __init__(self):
+        self.entries = {}
+        self.order = []
+        self.device = torch.device("cpu")
+        self.finalized = False
+
+    def add(self, name, kind, shape, store_shape=None, trainable=True, region=None):
+        assert not self.finalized and name not in self.entries
+        e = Entry(name, kind, shape, store_shape or shape, trainable)
+        e.region = region or ("train" if trainable else "frozen")
+        self.entries[name] = e
+        self.order.append(e)
+        return e
+
+    def finalize(self):
+        sizes = {"train": 0, "frozen": 0, "buf": 0}
+        for e in self.order:
+            e.offset = sizes[e.region]
+            sizes[e.region] += (e.numel + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.sizes = sizes
+        self.n_train = sizes["train"]
+        n_par = sizes["train"] + sizes["frozen"]
+        self.params = torch.zeros(max(n_par, 8), dtype=torch.float32)
+        self.bufs = torch.zeros(max(sizes["buf"], 8), dtype=torch.float32)
+        self.grads = None
+        self.shadow = None
+        self.finalized = True
+
+    def base(self, e):
+        return e.offset + (self.n_train if e.region == "frozen" else 0)
+
+    def storage(self, e, which="params"):
+        """1-D view of the entry inside a flat buffer."""
+        if e.region == "buf":
+            return self.bufs[e.offset:e.offset + e.numel]
+        flat = getattr(self, which)
+        b = self.base(e)
+        return flat[b:b + e.numel]
+
+    def logical_view(self, e, which="params"):
+        """View with the reference's logical shape (OIHW for convs) sharing the flat storage."""
+        s = self.storage(e, which)
+        if e.kind == "conv":
+            co, ci, kh, kw = e.shape
+            cop, _, _, cip = e.store_shape
+            return s.view(cop, kh, kw, cip)[:co, :, :, :ci].permute(0, 3, 1, 2)
+        return s.view(e.store_shape)[tuple(slice(0, d) for d in e.shape)]
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.params = self.params.to(device)
+        self.bufs = self.bufs.to(device)
+        if self.grads is not None:
+            self.grads = self.grads.to(device)
+        if self.shadow is not None:
+            self.shadow = self.shadow.to(device)
+
+    def ensure_grads(self):
+        if self.grads is None:
+            self.grads = torch.zeros(max(self.n_train, 8), dtype=torch.float32, device=self.params.device)
+
+    def ensure_shadow(self):
+        if self.shadow is None:
+            self.shadow = torch.empty(self.params.numel(), dtype=torch.bfloat16, device=self.params.device)
+        return self.shadow
+
+    def refresh_shadow(self):
+        sh = self.ensure_shadow()
+        ops.check(ops.lib.kd6d_cast_f32_to_bf16(ops._ptr(self.params), ops._ptr(sh), self.params.numel(),
+                                                ops._stream()), "kd6d_cast_f32_to_bf16")
+
+
+# ----------------------------------------------------------------------------------------
+# layers
+# ----------------------------------------------------------------------------------------
+class Conv:
+    """conv2d (+ optional bias) over 1..5 packed levels.  Weight entry is KRSC-stored."""
+
+    def __init__(self, net, name, cin, cout, k, stride=1, bias=True, trainable=True):
+        self.net, self.name = net, name
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        self.cin_p, self.cout_p = _pad8(cin), _pad8(cout)
+        st = net.store
+        self.w = st.add(name + ".weight", "conv", (cout, cin, k, k), (self.cout_p, k, k, self.cin_p), trainable)
+        self.b = st.add(name + ".bias", "vec", (cout,), (self.cout_p,), trainable) if bias else None
+        self.geoms = {}
+        self.wt_off = None     # offset inside the dgrad-packed weight buffer
+        net.convs.append(self)
+
+    def geom(self, batch, levels):
+        key = (batch, tuple(levels))
+        g = self.geoms.get(key)
+        if g is None:
+            g = ops.Geom(batch, self.cin_p, self.cout_p, self.k, self.stride, self.k // 2, list(levels))
+            self.geoms[key] = g
+        return g
+
+    # pointers into the flat buffers ------------------------------------------------------
+    def weight(self):
+        st = self.net.store
+        src = st.params if self.net.dtype == torch.float32 else st.shadow
+        b = st.base(self.w)
+        return src[b:b + self.w.numel]
+
+    def bias(self):
+        return None if self.b is None else self.net.store.storage(self.b)
+
+    def weight_t(self):
+        return self.net.wt[self.wt_off:self.wt_off + self.w.numel]
+
+    def flops(self, g):
+        """Algorithmic FLOPs of one pass (2*MAC on the reference's logical channel counts)."""
+        return 2 * g.rows_out * self.cout * self.k * self.k * self.cin
+
+    def fwd(self, x, batch, levels, out=None, scale=None, shift=None, act=ACT_NONE, residual=None,
+            seg_scale=None, out_f32=False):
+        g = self.geom(batch, levels)
+        if shift is None:
+            shift = self.bias()
+        return ops.conv2d_fwd(g, x, self.weight(), out=out, ch_scale=scale, ch_shift=shift, act=act,
+                              residual=residual, seg_scale=seg_scale, out_f32=out_f32, flops=self.flops(g)), g
+
+    def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False):
+        """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
+        st = self.net.store
+        g = self.geom(batch, levels)
+        ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g))
+        if self.b is not None:
+            ops.colstats(dy, st.storage(self.b, "grads"))
+        if not need_dx:
+            return None
+        return ops.conv2d_dgrad(g, dy, self.weight_t(), dx=dx, accumulate=accumulate, flops=self.flops(g))
+
+
+class BatchNorm:
+    def __init__(self, net, name, c, trainable=True):
+        st = net.store
+        self.net, self.c = net, c
+        self.gamma = st.add(name + ".weight", "vec", (c,), (c,), trainable)
+        self.beta = st.add(name + ".bias", "vec", (c,), (c,), trainable)
+        self.rm = st.add(name + ".running_mean", "vec", (c,), (c,), False, region="buf")
+        self.rv = st.add(name + ".running_var", "vec", (c,), (c,), False, region="buf")
+        self.nbt_index = len(net.bns)
+        net.bns.append((name, self))
+        self.fold = None
+
+    def folded(self):
+        """eval-mode scale/shift (computed once per weight load; torch ops = plumbing)."""
+        if self.fold is None:
+            st = self.net.store
+            scale = st.storage(self.gamma) * torch.rsqrt(st.storage(self.rv) + 1e-5)
+            shift = st.storage(self.beta) - st.storage(self.rm) * scale
+            self.fold = (scale.contiguous(), shift.contiguous())
+        return self.fold
+
+
+class ConvBlock:
+    """conv(no bias) + BN + LeakyReLU(0.1)  (backbone/common.py:250-324)."""
+
+    def __init__(self, net, name, cin, cout, k, stride=1):
+        self.net, self.name = net, name
+        self.conv = Conv(net, name + ".conv", cin, cout, k, stride, bias=False)
+        self.bn = BatchNorm(net, name + ".bn", self.conv.cout_p)
+        assert self.conv.cout_p == cout, "BN channels must already be a multiple of 8"
+
+    def fwd_eval(self, x, batch, levels, residual=None):
+        sc, sh = self.bn.folded()
+        y, g = self.conv.fwd(x, batch, levels, scale=sc, shift=sh, act=ACT_LEAKY, residual=residual)
+        return y, g.levels_out
+
+    def fwd_train(self, x, batch, levels, tape):
+        net, st = self.net, self.net.store
+        # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
+        raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
+                               out=net.buf(self.name + ".raw", (self.conv.geom(batch, levels).rows_out, self.conv.cout_p),
+                                           torch.float32))
+        c = self.conv.cout_p
+        s = net.scratch(self.name, 6 * c)
+        ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
+        ops.colstats(raw, ssum, ssq)
+        z = net.buf(self.name + ".z", raw.shape, net.dtype)
+        ops.bn_train_fwd(raw, z, ssum, ssq, st.storage(self.bn.gamma), st.storage(self.bn.beta), 1e-5, 0.1,
+                         st.storage(self.bn.rm), st.storage(self.bn.rv), mean, invstd, ACT_LEAKY)
+        tape.append((self, x, raw, batch, tuple(levels)))
+        return z, g.levels_out
+
+    def bwd(self, rec, dz, need_dx=True, dx=None, accumulate=False):
+        _, x, raw, batch, levels = rec
+        net, st = self.net, self.net.store
+        c = self.conv.cout_p
+        s = net.scratch(self.name, 6 * c)
+        mean, invstd, w1, w2 = s[2 * c:3 * c], s[3 * c:4 * c], s[4 * c:5 * c], s[5 * c:6 * c]
+        draw = net.buf(self.name + ".draw", raw.shape, net.dtype)
+        ops.bn_train_bwd(raw, dz, draw, mean, invstd, st.storage(self.bn.gamma), st.storage(self.bn.beta),
+                         ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"), st.storage(self.bn.beta, "grads"))
+        return self.conv.bwd(x, draw, batch, levels, need_dx=need_dx, dx=dx, accumulate=accumulate)
+
+
+class GroupNormReLU:
+    def __init__(self, net, name, c, groups=32):
+        st = net.store
+        self.net, self.name, self.c, self.groups = net, name, c, groups
+        self.gamma = st.add(name + ".weight", "vec", (c,), (c,), True)
+        self.beta = st.add(name + ".bias", "vec", (c,), (c,), True)
+
+    def fwd(self, x, batch, levels, out=None):
+        net, st = self.net, self.net.store
+        hw = [h * w for (h, w) in levels]
+        stats = net.buf(self.name + ".stats", (len(levels) * batch * self.groups * 2,), torch.float32)
+        if out is None:
+            out = net.buf(self.name + ".y", x.shape)
+        ops.gn_relu_fwd(x, out, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), 1e-5, stats)
+        return out
+
+    def bwd(self, x, dz, batch, levels, dx):
+        net, st = self.net, self.net.store
+        hw = [h * w for (h, w) in levels]
+        stats = net.buf(self.name + ".stats", (len(levels) * batch * self.groups * 2,), torch.float32)
+        gsum = net.buf(self.name + ".gsum", stats.shape, torch.float32)
+        ops.gn_relu_bwd(x, dz, dx, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), stats,
+                        gsum, st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"))
+        return dx
+
+
+# ----------------------------------------------------------------------------------------
+# the network
+# ----------------------------------------------------------------------------------------
+class PoseNet:
+    def __init__(self, arch, dtype=torch.bfloat16, n_class=16, n_conv=4, prior=0.01):
+        assert arch in BACKBONE_CFG, "Unsupported backbone %r" % (arch,)
+        self.arch, self.dtype = arch, dtype
+        self.store = ParamStore()
+        self.convs, self.bns = [], []
+        self._bufs, self._scratch_off, self._scratch_size, self.scratch_buf = {}, {}, 0, None
+        self.wt = None
+        self.training = True
+        feat, oc = BACKBONE_CFG[arch]
+        self.out_channel = oc
+        self.n_levels = 5 if arch == "darknet53" else 4
+        self.n_cls = n_class - 1
+        st = self.store
+        # ---- backbone ----
+        if arch == "darknet53":
+            self.init_block = ConvBlock(self, "backbone.features.init_block", 3, 32, 3)
+            self.stages = []
+            cin = 32
+            for i, (c, n) in enumerate(zip([64, 128, 256, 512, 1024], [2, 3, 9, 9, 5])):
+                units = []
+                for j in range(n):
+                    nm = "backbone.features.stage%d.unit%d" % (i + 1, j + 1)
+                    if j == 0:
+                        units.append(("down", ConvBlock(self, nm, cin, c, 3, 2)))
+                    else:
+                        units.append(("res", ConvBlock(self, nm + ".conv1", cin, c // 2, 1),
+                                      ConvBlock(self, nm + ".conv2", c // 2, c, 3)))
+                    cin = c
+                self.stages.append(units)
+            st.add("backbone.output.weight", "vec", (1000, 1024), (1000, 1024), False)
+            st.add("backbone.output.bias", "vec", (1000,), (1000,), False)
+        else:
+            self.stages = []
+            cin = 3
+            chans = TINY_CHANNELS[arch]
+            for i, per_stage in enumerate(chans):
+                units = []
+                for j, c in enumerate(per_stage):
+                    pointwise = len(per_stage) > 1 and (j % 2 == 0)     # darknet.py:92 with odd_pointwise
+                    units.append(ConvBlock(self, "backbone.features.stage%d.unit%d" % (i + 1, j + 1), cin, c,
+                                           1 if pointwise else 3))
+                    cin = c
+                self.stages.append(units)
+            st.add("backbone.output.final_conv.weight", "vec", (1000, cin, 1, 1), (1000, cin, 1, 1), False)
+            st.add("backbone.output.final_conv.bias", "vec", (1000,), (1000,), False)
+        # ---- FPN ----
+        self.inner, self.outc = {}, {}
+        for i, c in enumerate(feat):
+            if c == 0:
+                continue
+            self.inner[i] = Conv(self, "fpn.inner_convs.%d" % i, c, oc, 1)
+            self.outc[i] = Conv(self, "fpn.out_convs.%d" % i, oc, oc, 3)
+        self.p6 = Conv(self, "fpn.top_blocks.p6", feat[-1], oc, 3, 2)
+        self.p7 = Conv(self, "fpn.top_blocks.p7", oc, oc, 3, 2)
+        # ---- head ----
+        self.cls_tower, self.pose_tower = [], []
+        for t, tower in (("cls_tower", self.cls_tower), ("pose_tower", self.pose_tower)):
+            for i in range(n_conv):
+                tower.append((Conv(self, "head.%s.%d" % (t, 3 * i), oc, oc, 3),
+                              GroupNormReLU(self, "head.%s.%d" % (t, 3 * i + 1), oc)))
+        self.cls_logits = Conv(self, "head.cls_logits", oc, self.n_cls, 3)
+        self.pose_pred = Conv(self, "head.pose_pred", oc, self.n_cls * 16, 3)
+        self.scales = st.add("head.scales", "vec", (8,), (8,), True)          # slots 0..n_levels-1 used
+        for l in range(5):
+            if l >= self.n_levels:
+                st.add("head.scales.%d.scale" % l, "vec", (1,), (1,), False)
+        self.prior = prior
+        st.finalize()
+        self.reset_parameters()
+
+    # ---- parameters ----------------------------------------------------------------------
+    def named_logical(self):
+        """(reference name, logical-shape view) for every state_dict tensor except the anchors."""
+        st = self.store
+        out = []
+        for e in st.order:
+            if e.name == "head.scales":
+                for l in range(self.n_levels):
+                    out.append(("head.scales.%d.scale" % l, st.storage(e)[l:l + 1], True))
+                continue
+            out.append((e.name, st.logical_view(e), e.region != "buf"))
+        return out
+
+    def reset_parameters(self, seed=None):
+        """Reference initialisation (darknet*.py:_init_params, model.py:22-37,420-433)."""
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        st = self.store
+        for e in st.order:
+            v = st.logical_view(e) if e.name != "head.scales" else st.storage(e)
+            if e.name == "head.scales" or e.name.endswith(".scale"):
+                v.fill_(1.0)
+            elif e.name.endswith("running_var"):
+                v.fill_(1.0)
+            elif e.name.endswith("running_mean"):
+                v.zero_()
+            elif e.kind == "conv":
+                fan_in = e.shape[1] * e.shape[2] * e.shape[3]
+                if e.name.startswith("head."):
+                    v.copy_(torch.randn(e.shape, generator=g) * 0.01)
+                else:
+                    a = 1.0 if e.name.startswith("fpn.") else 0.0
+                    bound = math.sqrt(2.0 / (1 + a * a)) * math.sqrt(3.0 / fan_in)
+                    v.copy_((torch.rand(e.shape, generator=g) * 2 - 1) * bound)
+            elif e.name.endswith("bn.weight") or (e.name.startswith("head.") and e.name.endswith(".weight")):
+                v.fill_(1.0)          # BN / GN gamma
+            elif e.name == "head.cls_logits.bias":
+                v.fill_(-math.log((1 - self.prior) / self.prior))
+            elif e.name.startswith("backbone.output"):
+                v.copy_(torch.randn(e.shape, generator=g) * 0.01 if len(e.shape) > 1 else torch.zeros(e.shape))
+            else:
+                v.zero_()
+        self.invalidate()
+
+    def invalidate(self):
+        for _, bn in self.bns:
+            bn.fold = None
+        self._weights_dirty = True
+
+    def to(self, device):
+        self.store.to(device)
+        self._bufs.clear()
+        self.scratch_buf = None
+        self.wt = None
+        self.invalidate()
+        return self
+
+    @property
+    def device(self):
+        return self.store.params.device
+
+    # ---- workspaces ----------------------------------------------------------------------
+    def buf(self, name, shape, dtype=None):
+        dtype = dtype or self.dtype
+        key = (name, tuple(shape), dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    SCRATCH_FLOATS = 1 << 18
+
+    def scratch(self, name, n):
+        """fp32 slice of the per-step scratch arena (zeroed once per step by the training forward)."""
+        off = self._scratch_off.get(name)
+        if off is None:
+            off = self._scratch_size
+            self._scratch_off[name] = off
+            self._scratch_size += (n + 7) // 8 * 8
+            assert self._scratch_size <= self.SCRATCH_FLOATS, "scratch arena too small"
+        if self.scratch_buf is None:
+            self.scratch_buf = torch.zeros(self.SCRATCH_FLOATS, dtype=torch.float32, device=self.device)
+        return self.scratch_buf[off:off + n]
+
+    def prepare_weights(self, need_dgrad):
+        """bf16 shadow + dgrad packing (one launch each) whenever the master weights changed."""
+        st = self.store
+        if self.dtype == torch.bfloat16 and (self._weights_dirty or st.shadow is None):
+            st.refresh_shadow()
+        if need_dgrad:
+            if self.wt is None:
+                off, blk, desc = 0, 0, []
+                self._dgrad_layers = [c for c in self.convs if c.w.trainable]
+                for c in self._dgrad_layers:
+                    c.wt_off = off
+                    desc += [st.base(c.w), off, c.cout_p, c.cin_p, c.k, blk]
+                    off += c.w.numel
+                    blk += (c.w.numel + 2047) // 2048
+                self.wt = torch.empty(off, dtype=self.dtype, device=self.device)
+                self._dgrad_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
+                self._dgrad_blocks = blk
+            src = st.params if self.dtype == torch.float32 else st.shadow
+            ops.pack_dgrad_weights(src, self.wt, self._dgrad_desc, len(self._dgrad_layers), self._dgrad_blocks)
+        self._weights_dirty = False
+
+    # ---- forward ---------------------------------------------------------------------------
+    def _backbone53(self, x, B, lv):
+        x, lv = self.init_block.fwd_eval(x, B, lv) if not self.training else self.init_block.fwd_train(x, B, lv, self.tape)
+        feats = []
+        for units in self.stages:
+            for u in units:
+                if u[0] == "down":
+                    x, lv = u[1].fwd_eval(x, B, lv) if not self.training else u[1].fwd_train(x, B, lv, self.tape)
+                else:
+                    if self.training:
+                        raise NotImplementedError("darknet53 is only run as the frozen teacher (eval mode) "
+                                                  "in the KD step; training it is outside the hot path")
+                    h, _ = u[1].fwd_eval(x, B, lv)
+                    x, lv = u[2].fwd_eval(h, B, lv, residual=x)
+            feats.append((x, lv))
+        return feats
+
+    def _backbone_tiny(self, x, B, lv):
+        feats = []
+        n = len(self.stages)
+        for i, units in enumerate(self.stages):
+            for u in units:
+                x, lv = u.fwd_train(x, B, lv, self.tape) if self.training else u.fwd_eval(x, B, lv)
+            if i != n - 1:
+                (h, w) = lv[0]
+                y = self.buf("pool%d" % i, (B * (h // 2) * (w // 2), x.shape[1]))
+                ops.maxpool2_fwd(x, y, B, h, w)
+                if self.training:
+                    self.tape.append(("pool", x, B, h, w))
+                x, lv = y, [(h // 2, w // 2)]
+            feats.append((x, lv))
+        # darknet.py:125-135: out4 = stage5(stage4(out3))
+        return [feats[0], feats[1], feats[2], feats[4]]
+
+    def forward(self, images):
+        """images (B,3,H,W) fp32 NCHW on device -> packed logits cls (rows,16) fp32, reg (rows,240) fp32."""
+        B, _, H, W = images.shape
+        self.prepare_weights(need_dgrad=self.training)
+        self.tape = []
+        x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=self.buf("input", (B * H * W, 8)))
+        feats = self._backbone53(x, B, [(H, W)]) if self.arch == "darknet53" else self._backbone_tiny(x, B, [(H, W)])
+        oc = self.out_channel
+        idxs = sorted(self.inner.keys())
+        top = idxs[-1]
+        levels = [feats[i][1][0] for i in idxs]
+        h6 = ((levels[-1][0] + 1) // 2, (levels[-1][1] + 1) // 2)
+        h7 = ((h6[0] + 1) // 2, (h6[1] + 1) // 2)
+        levels_all = levels + [h6, h7]
+        row0, r = [], 0
+        for (h, w) in levels_all:
+            row0.append(r)
+            r += B * h * w
+        head_in = self.buf("head_in", (r, oc))
+        self.levels, self.rows, self.level_row0, self.batch = levels_all, r, row0, B
+
+        def slot(li):
+            h, w = levels_all[li]
+            return head_in[row0[li]:row0[li] + B * h * w]
+
+        inner_prev = None
+        self.fpn_ctx = {}
+        for pos in range(len(idxs) - 1, -1, -1):
+            i = idxs[pos]
+            f, lv = feats[i]
+            h, w = lv[0]
+            if inner_prev is None:
+                inner, _ = self.inner[i].fwd(f, B, lv, out=self.buf("inner%d" % i, (B * h * w, oc)))
+            else:
+                lat, _ = self.inner[i].fwd(f, B, lv, out=self.buf("lat%d" % i, (B * h * w, oc)))
+                inner = ops.upsample2_add(lat, inner_prev, self.buf("inner%d" % i, (B * h * w, oc)), B, h, w)
+            self.outc[i].fwd(inner, B, lv, out=slot(pos))
+            self.fpn_ctx[i] = (f, lv, inner)
+            inner_prev = inner
+        ftop, lvtop = feats[top]
+        p6, _ = self.p6.fwd(ftop, B, lvtop, out=slot(len(idxs)))
+        p6r = ops.eltwise(ops.ELT_RELU, p6, None, self.buf("p6_relu", p6.shape))
+        self.p7.fwd(p6r, B, [h6], out=slot(len(idxs) + 1))
+        self.p6_ctx = (ftop, lvtop, p6, p6r, h6)
+        # ---- head over all levels at once ----
+        self.head_ctx = {}
+        outs = {}
+        for tname, tower, final in (("cls", self.cls_tower, self.cls_logits), ("pose", self.pose_tower, self.pose_pred)):
+            x = head_in
+            saved = []
+            for li, (conv, gn) in enumerate(tower):
+                raw, _ = conv.fwd(x, B, levels_all, out_f32=True,
+                                  out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32))
+                y = gn.fwd(raw, B, levels_all, out=self.buf("%s.act%d" % (tname, li), (r, oc)))
+                saved.append((x, raw))
+                x = y
+            seg = self.store.storage(self.scales) if tname == "pose" else None
+            out, _ = final.fwd(x, B, levels_all, seg_scale=seg, out_f32=True,
+                               out=self.buf("%s.logits" % tname, (r, final.cout_p), torch.float32))
+            self.head_ctx[tname] = (saved, x)
+            outs[tname] = out
+        return outs["cls"], outs["pose"]
+
+    # ---- backward (student only) -------------------------------------------------------------
+    def backward(self, dcls, dreg):
+        """dcls (rows,16), dreg (rows,240) in self.dtype: gradients w.r.t. the UNSCALED head outputs
+        (the Scale module's factor is already folded into dreg by kd6d_loss_backward)."""
+        assert self.training and self.arch != "darknet53"
+        B, lv_all, r, oc = self.batch, self.levels, self.rows, self.out_channel
+        d_head_in = self.buf("d_head_in", (r, oc))
+        first = True
+        for tname, tower, final, dlog in (("cls", self.cls_tower, self.cls_logits, dcls),
+                                          ("pose", self.pose_tower, self.pose_pred, dreg)):
+            saved, last = self.head_ctx[tname]
+            dx = final.bwd(last, dlog, B, lv_all, dx=self.buf("%s.dact" % tname, (r, oc)))
+            for li in range(len(tower) - 1, -1, -1):
+                conv, gn = tower[li]
+                x_in, raw = saved[li]
+                draw = gn.bwd(raw, dx, B, lv_all, self.buf("%s.draw" % tname, (r, oc)))
+                if li > 0:
+                    dx = conv.bwd(x_in, draw, B, lv_all, dx=self.buf("%s.dact" % tname, (r, oc)))
+                else:
+                    conv.bwd(x_in, draw, B, lv_all, dx=d_head_in, accumulate=not first)
+            first = False
+        row0 = self.level_row0
+
+        def dslot(li):
+            h, w = lv_all[li]
+            return d_head_in[row0[li]:row0[li] + B * h * w]
+
+        idxs = sorted(self.inner.keys())
+        n_l = len(idxs)
+        # P7 = conv(relu(P6)); P6 = conv(top feature)
+        ftop, lvtop, p6, p6r, h6 = self.p6_ctx
+        d_p6r = self.p7.bwd(p6r, dslot(n_l + 1), B, [h6], dx=self.buf("d_p6r", p6.shape))
+        d_p6 = ops.eltwise(ops.ELT_RELU_BWD, p6, d_p6r, self.buf("d_p6a", p6.shape))
+        d_p6 = ops.eltwise(ops.ELT_ADD, d_p6, dslot(n_l), self.buf("d_p6", p6.shape))
+        dfeat = {}
+        top = idxs[-1]
+        dfeat[top] = self.p6.bwd(ftop, d_p6, B, lvtop, dx=self.buf("dfeat%d" % top, ftop.shape))
+        d_inner_up = None
+        for pos in range(n_l):
+            i = idxs[pos]
+            f, lv, inner = self.fpn_ctx[i]
+            h, w = lv[0]
+            d_inner = self.buf("d_inner%d" % i, inner.shape)
+            if d_inner_up is not None:
+                ops.sumpool2(d_inner_up[0], d_inner, B, d_inner_up[1], d_inner_up[2])
+                self.outc[i].bwd(inner, dslot(pos), B, lv, dx=d_inner, accumulate=True)
+            else:
+                self.outc[i].bwd(inner, dslot(pos), B, lv, dx=d_inner)
+            if i == top:
+                self.inner[i].bwd(f, d_inner, B, lv, dx=dfeat[top], accumulate=True)
+            else:
+                dfeat[i] = self.inner[i].bwd(f, d_inner, B, lv, dx=self.buf("dfeat%d" % i, f.shape))
+            d_inner_up = (d_inner, h, w)
+        # ---- backbone (tiny): walk the tape in reverse ----
+        # feats index -> gradient arriving from the FPN; out4 = index 3 (after stage 5), out3 = index 2
+        grad = dfeat[top]
+        pending = {2: dfeat.get(2)}            # added when the sweep reaches out3 (after pool3)
+        stage_of_pool = {}
+        i_rec = len(self.tape) - 1
+        pools_seen = 0
+        n_pools = sum(1 for t in self.tape if t[0] == "pool")
+        while i_rec >= 0:
+            rec = self.tape[i_rec]
+            if rec[0] == "pool":
+                _, x, b_, h, w = rec
+                pool_idx = n_pools - 1 - pools_seen    # 3,2,1,0
+                pools_seen += 1
+                if pool_idx == 2 and pending[2] is not None:
+                    grad = ops.eltwise(ops.ELT_ADD, grad, pending[2], self.buf("d_out3", grad.shape))
+                dx = self.buf("dpool%d" % pool_idx, x.shape)
+                grad = ops.maxpool2_bwd(x, grad, dx, b_, h, w)
+            else:
+                blk = rec[0]
+                need_dx = i_rec > 0
+                grad = blk.bwd(rec, grad, need_dx=need_dx,
+                               dx=self.buf(blk.name + ".dx", rec[1].shape) if need_dx else None)
+            i_rec -= 1
+        return None

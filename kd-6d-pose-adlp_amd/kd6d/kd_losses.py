@@ -1,0 +1,198 @@
+"""Host orchestration of the loss side of the KD step (no arithmetic: kernel launches only).
+
+Replaces the Python of losses/kd_loss.py:111-160 (KDPoseLoss.__call__), :40-109
+(KDObjectSpaceLoss), losses/loss_libs.py:1-51 (kd_loss_2d), losses/loss.py:164-268
+(prepare_targets) and postprocess/postprocess_kd.py (teacher knowledge) with one launch each and
+no device->host synchronisation anywhere in the step.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import Levels, check, lib
+
+ANCHOR_SIZES = [32, 64, 128, 256, 512]
+ANCHOR_STRIDES = [8, 16, 32, 64, 128]
+CAP = 32          # slots per image for positives / teacher cells (reference: ~10, POSITIVE_NUM)
+MAX_GT = _lib.MAX_GT
+
+
+def make_levels(batch, shapes, sizes=ANCHOR_SIZES, strides=ANCHOR_STRIDES):
+    lv = Levels()
+    lv.n, lv.batch = len(shapes), batch
+    for i in range(_lib.MAX_SEG):
+        lv.anchor_size[i] = float(sizes[i])
+        lv.anchor_stride[i] = float(strides[i])
+        if i < len(shapes):
+            lv.h[i], lv.w[i] = shapes[i]
+    return lv
+
+
+class PackedTargets:
+    """list[PoseAnnot] -> dense device tensors, padded to MAX_GT instances per image."""
+
+    def __init__(self, targets, device):
+        B = len(targets)
+        self.batch = B
+        f32 = dict(dtype=torch.float32, device=device)
+        self.mask = torch.stack([t.mask.to(device=device, dtype=torch.float32) for t in targets]).contiguous()
+        self.mask_h, self.mask_w = int(self.mask.shape[1]), int(self.mask.shape[2])
+        self.kp3d = torch.stack([t.keypoints_3d.to(**f32) for t in targets]).contiguous()     # (B,15,8,3)
+        self.K = torch.stack([t.K.to(**f32) for t in targets]).contiguous()
+        self.bbox_trans = torch.stack([t.bbox_trans.to(**f32) for t in targets]).contiguous()
+        cls = torch.full((B, MAX_GT), 0, dtype=torch.int32)
+        ngt = torch.zeros(B, dtype=torch.int32)
+        rot = torch.zeros(B, MAX_GT, 3, 3)
+        tr = torch.zeros(B, MAX_GT, 3)
+        same_dev = all(t.class_ids.device == torch.device(device) for t in targets) and torch.device(device).type != "cpu"
+        if same_dev:
+            # inputs already resident on the device: assemble there (no host round trip)
+            cls, ngt, rot, tr = cls.to(device), ngt.to(device), rot.to(device), tr.to(device)
+        for i, t in enumerate(targets):
+            g = min(len(t.class_ids), MAX_GT)
+            if len(t.class_ids) > MAX_GT:
+                raise ValueError("kd6d_ssc_assign handles at most %d instances per image" % MAX_GT)
+            cls[i, :g] = t.class_ids[:g].to(torch.int32)
+            ngt[i] = g
+            rot[i, :g] = t.rotations[:g].to(torch.float32)
+            tr[i, :g] = t.translations[:g].reshape(g, 3).to(torch.float32)
+        self.class_ids = cls.to(device).contiguous()
+        self.n_gt = ngt.to(device).contiguous()
+        self.rot = rot.to(device).contiguous()
+        self.trans = tr.to(device).contiguous()
+        self.frame_wh = (640.0, 480.0)        # kd_loss.py:116-117 ("not 256")
+
+
+class TeacherKnowledge(dict):
+    """pred_t of the reference (models/model_kd.py:83-92).  The device-side slot arrays are what the
+    student step consumes; the reference-named entries are materialised (with a sync) on demand."""
+
+    def __init__(self, t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta, cap, batch):
+        super().__init__()
+        self.t_cnt, self.t_kp, self.t_score, self.t_row = t_cnt, t_kp, t_score, t_row
+        self.t_kp_norm, self.t_beta = t_kp_norm, t_beta
+        self.cap, self.batch = cap, batch
+        self.t_start = torch.arange(batch, dtype=torch.int32, device=t_cnt.device) * cap
+
+    def __missing__(self, key):
+        if key not in ("post_kp_2d", "post_kp_cls", "post_pos_per_img"):
+            raise KeyError(key)
+        cnt = self.t_cnt.cpu().tolist()
+        kp = torch.cat([self.t_kp[b * self.cap:b * self.cap + n] for b, n in enumerate(cnt)]) if self.batch else self.t_kp[:0]
+        sc = torch.cat([self.t_score[b * self.cap:b * self.cap + n] for b, n in enumerate(cnt)]) if self.batch else self.t_score[:0]
+        self["post_kp_2d"], self["post_kp_cls"], self["post_pos_per_img"] = kp, sc, cnt
+        return dict.__getitem__(self, key)
+
+
+def teacher_select(cls_t, reg_t, levels, batch, bbox_trans, th=0.1, positive_num=10, positive_lambda=1.0, cap=CAP,
+                   frame_wh=(640.0, 480.0)):
+    dev = cls_t.device
+    lv = make_levels(batch, levels)
+    t_cnt = torch.zeros(batch, dtype=torch.int32, device=dev)
+    t_kp = torch.zeros(batch * cap, 8, 2, dtype=torch.float32, device=dev)
+    t_score = torch.zeros(batch * cap, 8, dtype=torch.float32, device=dev)
+    t_row = torch.zeros(batch * cap, dtype=torch.int32, device=dev)
+    t_kp_n = torch.zeros_like(t_kp)
+    t_beta = torch.zeros_like(t_score)
+    check(lib.kd6d_teacher_select(ctypes.byref(lv), ops._ptr(cls_t), ops._ptr(reg_t), ops._ptr(bbox_trans),
+                                  th, float(positive_num), float(positive_lambda), cap, frame_wh[0], frame_wh[1],
+                                  ops._ptr(t_cnt), ops._ptr(t_kp), ops._ptr(t_score), ops._ptr(t_row),
+                                  ops._ptr(t_kp_n), ops._ptr(t_beta), ops._stream()),
+          "kd6d_teacher_select")
+    return TeacherKnowledge(t_cnt, t_kp, t_score, t_row, t_kp_n, t_beta, cap, batch)
+
+
+class KDLoss:
+    """Student-side losses of one step.  forward() launches; backward(weights) fills dcls/dreg."""
+
+    def __init__(self, internal_K, diameters, gamma=2.0, alpha=0.25, positive_num=10, positive_lambda=1.0,
+                 kd_cfg=None, cap=CAP):
+        K = np.asarray(internal_K, np.float64).reshape(3, 3)
+        self.kinv = (ctypes.c_float * 9)(*np.linalg.inv(K).reshape(-1).astype(np.float32).tolist())
+        self.diameters_host = [float(d) for d in diameters]
+        self.diameters = None
+        self.gamma, self.alpha = float(gamma), float(alpha)
+        self.positive_num, self.positive_lambda = float(positive_num), float(positive_lambda)
+        kd_cfg = kd_cfg or {}
+        if kd_cfg.get("GTYPE", "sinkhorn") != "sinkhorn":
+            raise NotImplementedError("only --gtype sinkhorn is implemented on the HIP path (got %r)" % kd_cfg.get("GTYPE"))
+        if kd_cfg.get("GLEVEL", "point") != "point" or int(kd_cfg.get("GnD", 2)) != 2:
+            raise NotImplementedError("only --glevel point / --gnD 2 are implemented")
+        self.p = float(kd_cfg.get("GP", 2.0))
+        self.blur = float(kd_cfg.get("GBLUR", 0.001))
+        self.scaling = float(kd_cfg.get("SCALING", 0.5))
+        reach = kd_cfg.get("REACH", 0.5)
+        self.reach = -1.0 if reach is None else float(reach)
+        self.weighted = bool(kd_cfg.get("WEIGHTED_OT", True))
+        self.detach = bool(kd_cfg.get("DETACH", False))
+        if not self.weighted:
+            raise NotImplementedError("unweighted OT (--weightedOT false) is not implemented on the HIP path")
+        self.cap = cap
+        self.ctx = None
+
+    def forward(self, cls_s, reg_s, levels, batch, tgt, teacher, keys=None, seg_scale=None):
+        dev = cls_s.device
+        rows = cls_s.shape[0]
+        cap = self.cap
+        lv = make_levels(batch, levels)
+        if self.diameters is None or self.diameters.device != dev:
+            self.diameters = torch.tensor(self.diameters_host, dtype=torch.float32, device=dev)
+        if keys is None:
+            keys = torch.rand(rows, dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        labels = torch.empty(rows, **i32)
+        pos_cnt = torch.zeros(batch, **i32)
+        pos_row = torch.zeros(batch * cap, **i32)
+        pos_gt = torch.zeros(batch * cap, **i32)
+        st = ops._stream()
+        P = ops._ptr
+        check(lib.kd6d_ssc_assign(ctypes.byref(lv), P(tgt.mask), tgt.mask_h, tgt.mask_w, P(tgt.kp3d), P(tgt.K),
+                                  P(tgt.class_ids), P(tgt.n_gt), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
+                                  P(keys), self.positive_num, self.positive_lambda, cap, P(labels), P(pos_cnt),
+                                  P(pos_row), P(pos_gt), st), "kd6d_ssc_assign")
+        losses = torch.zeros(4, **f32)         # cls, reg, kd, (pad)
+        check(lib.kd6d_focal_fwd(P(cls_s), P(labels), rows, self.gamma, self.alpha, P(losses[0:1]), st),
+              "kd6d_focal_fwd")
+        xs = torch.zeros(batch * cap, 8, 2, **f32)
+        alpha = torch.zeros(batch * cap, 8, **f32)
+        g_reg = torch.zeros(batch * cap, 8, 2, **f32)
+        s_start = torch.empty(batch, **i32)
+        fw, fh = tgt.frame_wh
+        check(lib.kd6d_student_points(ctypes.byref(lv), P(cls_s), P(reg_s), P(pos_cnt), P(pos_row), P(pos_gt),
+                                      P(tgt.class_ids), P(tgt.kp3d), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
+                                      P(self.diameters), self.kinv, fw, fh, cap, P(xs), P(alpha), P(g_reg),
+                                      P(losses[1:2]), P(s_start), st), "kd6d_student_points")
+        n_valid = torch.zeros(1, **i32)
+        valid = torch.zeros(batch, **i32)
+        g_xs = torch.zeros_like(xs)
+        g_alpha = torch.zeros_like(alpha)
+        if teacher is not None:
+            loss_img = torch.zeros(batch, **f32)
+            check(lib.kd6d_sinkhorn_div_fwd_bwd(P(xs), P(alpha), P(s_start), P(pos_cnt), P(teacher.t_kp_norm),
+                                                P(teacher.t_beta), P(teacher.t_start), P(teacher.t_cnt), batch, self.p,
+                                                self.blur, self.scaling, self.reach, P(loss_img), P(valid),
+                                                P(g_xs), P(g_alpha), st), "kd6d_sinkhorn_div_fwd_bwd")
+            check(lib.kd6d_kd_mean(P(loss_img), P(valid), batch, P(losses[2:3]), P(n_valid), st), "kd6d_kd_mean")
+        self.ctx = dict(lv=lv, cls=cls_s, reg=reg_s, labels=labels, pos_cnt=pos_cnt, pos_row=pos_row, pos_gt=pos_gt,
+                        tgt=tgt, g_reg=g_reg, g_xs=g_xs, g_alpha=g_alpha, n_valid=n_valid, valid=valid,
+                        rows=rows, batch=batch, xs=xs, alpha=alpha, seg_scale=seg_scale, losses=losses)
+        return losses
+
+    def backward(self, weights, dtype, dcls, dreg, dseg_scale=None):
+        """weights: device fp32 tensor {d/d loss_cls, d/d loss_reg, d/d loss_kd}.  dreg must be zeroed."""
+        c = self.ctx
+        P = ops._ptr
+        st = ops._stream()
+        tgt = c["tgt"]
+        fw, fh = tgt.frame_wh
+        check(lib.kd6d_focal_bwd(ops.dt_code(dtype), P(c["cls"]), P(c["labels"]), c["rows"], self.gamma, self.alpha,
+                                 P(weights[0:1]), P(dcls), st), "kd6d_focal_bwd")
+        check(lib.kd6d_loss_backward(ctypes.byref(c["lv"]), ops.dt_code(dtype), P(c["cls"]), P(c["reg"]),
+                                     P(c["pos_cnt"]), P(c["pos_row"]), P(c["pos_gt"]), P(tgt.class_ids),
+                                     P(tgt.bbox_trans), P(c["g_reg"]), P(c["g_xs"]), P(c["g_alpha"]),
+                                     P(c["n_valid"]), P(c["valid"]), P(weights), P(c["seg_scale"]),
+                                     P(dseg_scale), fw, fh, self.cap, int(self.detach), P(dcls), P(dreg), st),
+              "kd6d_loss_backward")

@@ -1,0 +1,209 @@
+"""PoseModuleKD -- drop-in for models/model_kd.py:14-95 of the reference, on the kd6d engine.
+
+Same constructor (`PoseModuleKD(cfg, backbone)`), same forward signature and return values
+(train: `(None, {'loss_cls','loss_reg','loss_kd'})`; eval + is_teacher: the `pred_t` dict), same
+state_dict keys/shapes.  Internally nothing is a torch op: the forward runs
+HIP kernels over packed NHWC buffers, the three returned loss scalars carry an autograd node
+whose backward() launches the hand-written reverse sweep, and every nn.Parameter is a view into
+one flat fp32 buffer (its .grad a view into one flat gradient buffer).
+"""
+import torch
+from torch import nn
+
+from .. import engine, kd_losses, ops
+from ..kd_losses import KDLoss, PackedTargets, TeacherKnowledge
+
+
+class _Shell(nn.Module):
+    """Container used only to reproduce the reference's parameter hierarchy."""
+
+
+def _get_shell(root, dotted):
+    m = root
+    for part in dotted:
+        nxt = m._modules.get(part)
+        if nxt is None:
+            nxt = _Shell()
+            m.add_module(part, nxt)
+        m = nxt
+    return m
+
+
+class _StepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, losses, module):
+        ctx.module = module
+        return losses[0].clone(), losses[1].clone(), losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, g_kd):
+        m = ctx.module
+        dev = m.net.device
+        z = torch.zeros((), dtype=torch.float32, device=dev)
+        w = torch.stack([g if g is not None else z for g in (g_cls, g_reg, g_kd)]).to(torch.float32).contiguous()
+        m._run_backward(w)
+        return torch.zeros_like(m._anchor), None, None
+
+
+class PoseModuleKD(nn.Module):
+    def __init__(self, cfg, backbone):
+        super().__init__()
+        arch = getattr(backbone, "arch", None) or cfg["MODEL"]["BACKBONE"]
+        prec = cfg.get("RUNTIME", {}).get("PRECISION", "bf16")
+        dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[prec]
+        self.cfg = cfg
+        self.net = engine.PoseNet(arch, dtype, n_class=cfg["DATASETS"]["N_CLASS"], n_conv=cfg["MODEL"]["N_CONV"],
+                                  prior=cfg["MODEL"]["PRIOR"])
+        feat, oc = engine.BACKBONE_CFG[arch]
+        assert list(cfg["MODEL"]["FEAT_CHANNELS"]) == feat and cfg["MODEL"]["OUT_CHANNEL"] == oc, \
+            "cfg FEAT_CHANNELS/OUT_CHANNEL do not match backbone %s" % arch
+        self.inference_th = cfg["TEST"]["CONFIDENCE_TH"]
+        self.positive_num = cfg["SOLVER"]["POSITIVE_NUM"]
+        self.positive_lambda = cfg["SOLVER"]["POSITIVE_LAMBDA"]
+        if cfg["SOLVER"]["POSITIVE_TYPE"] != "SSC" or cfg["SOLVER"]["LOSS_REG_TYPE"] != "3D" or \
+                cfg["SOLVER"]["REGRESSION_TYPE"] != "POINT":
+            raise NotImplementedError("the HIP path implements POSITIVE_TYPE=SSC, LOSS_REG_TYPE=3D, REGRESSION_TYPE=POINT")
+        kd = cfg.get("KD", {})
+        if "LEVEL" in kd and kd["LEVEL"] != "pred":
+            raise KeyError("Ooops, KD from %s is not defined." % kd["LEVEL"])
+        self.loss_evaluator = KDLoss(cfg["INPUT"]["INTERNAL_K"], cfg["DATASETS"]["MESH_DIAMETERS"],
+                                     cfg["SOLVER"]["FOCAL_GAMMA"], cfg["SOLVER"]["FOCAL_ALPHA"], self.positive_num,
+                                     self.positive_lambda, kd if "GTYPE" in kd else None)
+        # ---- parameters / buffers under the reference names, as views of the flat store ----
+        self._names = []
+        for name, view, is_param in self.net.named_logical():
+            parts = name.split(".")
+            shell = _get_shell(self, parts[:-1])
+            if is_param:
+                shell.register_parameter(parts[-1], nn.Parameter(view, requires_grad=True))
+            else:
+                shell.register_buffer(parts[-1], view)
+            self._names.append((name, is_param))
+        self._nbt = torch.zeros(max(len(self.net.bns), 1), dtype=torch.long)
+        for i, (bn_name, _) in enumerate(self.net.bns):
+            _get_shell(self, bn_name.split(".")).register_buffer("num_batches_tracked", self._nbt[i])
+        ag = _get_shell(self, ["anchor_generator", "cell_anchors"])
+        for i, (s, st) in enumerate(zip(engine.ANCHOR_SIZES, engine.ANCHOR_STRIDES)):
+            c = st / 2.0
+            ag.register_buffer(str(i), torch.tensor([[c - 0.5 * (s - 1)] * 2 + [c + 0.5 * (s - 1)] * 2], dtype=torch.float32))
+        self._anchor = torch.zeros(1, requires_grad=True)
+        if getattr(backbone, "pretrained_file", None):
+            sd = torch.load(backbone.pretrained_file, map_location="cpu")
+            own = self.state_dict()
+            self.load_state_dict({k: v for k, v in {("backbone." + k): v for k, v in sd.items()}.items()
+                                  if k in own and own[k].shape == v.shape}, strict=False)
+
+    # ---- nn.Module plumbing ---------------------------------------------------------------
+    def _bind(self):
+        st = self.net.store
+        views = {n: v for n, v, _ in self.net.named_logical()}
+        for name, is_param in self._names:
+            parts = name.split(".")
+            shell = _get_shell(self, parts[:-1])
+            if is_param:
+                shell._parameters[parts[-1]].data = views[name]
+            else:
+                shell._buffers[parts[-1]] = views[name]
+        self._nbt = self._nbt.to(self.net.device)
+        for i, (bn_name, _) in enumerate(self.net.bns):
+            _get_shell(self, bn_name.split("."))._buffers["num_batches_tracked"] = self._nbt[i]
+        ag = _get_shell(self, ["anchor_generator", "cell_anchors"])
+        for k in list(ag._buffers.keys()):
+            ag._buffers[k] = ag._buffers[k].to(self.net.device)
+        self._anchor = torch.zeros(1, device=self.net.device, requires_grad=True)
+        self._bind_grads()
+
+    def _bind_grads(self):
+        st = self.net.store
+        if st.grads is None:
+            return
+        for e in st.order:
+            if e.region != "train":
+                continue
+            if e.name == "head.scales":
+                for l in range(self.net.n_levels):
+                    p = _get_shell(self, ["head", "scales", str(l)])._parameters["scale"]
+                    p.grad = st.storage(e, "grads")[l:l + 1]
+                continue
+            parts = e.name.split(".")
+            p = _get_shell(self, parts[:-1])._parameters[parts[-1]]
+            p.grad = st.logical_view(e, "grads")
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self.net.device))
+        if probe.dtype != torch.float32:
+            raise TypeError("PoseModuleKD keeps fp32 master parameters; choose bf16 compute with "
+                            "cfg['RUNTIME']['PRECISION'], not module.half()/bfloat16()")
+        if probe.device != self.net.device:
+            self.net.to(probe.device)
+            self._bind()
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        st = self.net.store
+        st.ensure_grads()
+        if self._parameters or True:
+            first = _get_shell(self, ["head", "cls_logits"])._parameters["weight"]
+            if first.grad is None:
+                self._bind_grads()
+        st.grads.zero_()
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        return type(sd)((k, v.detach().clone().contiguous()) for k, v in sd.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self.net.invalidate()
+        return out
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.net.training = mode
+        return self
+
+    # ---- the hot path ---------------------------------------------------------------------
+    def forward(self, images, targets, is_teacher=False, pred_t=None, cfg_kd=None):
+        x = images.tensors if hasattr(images, "tensors") else images
+        if x.device != self.net.device:
+            raise RuntimeError("images are on %s but the model is on %s" % (x.device, self.net.device))
+        B = x.shape[0]
+        net = self.net
+        if self.training:
+            st = net.store
+            st.ensure_grads()
+            if net.scratch_buf is not None:
+                net.scratch_buf.zero_()
+            cls, reg = net.forward(x)
+            tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
+            teacher = pred_t if isinstance(pred_t, TeacherKnowledge) else None
+            if pred_t is not None and teacher is None:
+                raise TypeError("pred_t must come from a kd6d teacher forward (TeacherKnowledge)")
+            losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher,
+                                                 keys=getattr(self, "_debug_keys", None),
+                                                 seg_scale=st.storage(net.scales))
+            self._nbt += 1
+            l_cls, l_reg, l_kd = _StepFn.apply(self._anchor, losses, self)
+            return None, {"loss_cls": l_cls, "loss_reg": l_reg, "loss_kd": l_kd}
+        if is_teacher:
+            cls, reg = net.forward(x)
+            tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
+            return kd_losses.teacher_select(cls, reg, net.levels, B, tgt.bbox_trans, self.inference_th,
+                                            self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh)
+        raise NotImplementedError("eval-mode pose inference (postprocess/postprocess.py, RANSAC-EPnP) is outside the "
+                                  "KD-step hot path (SURVEY.md 8(f)-2)")
+
+    def _run_backward(self, weights):
+        net, st = self.net, self.net.store
+        first = _get_shell(self, ["head", "cls_logits"])._parameters["weight"]
+        if first.grad is None:
+            self._bind_grads()
+        rows = net.rows
+        dcls = net.buf("dcls", (rows, 16))
+        dreg = net.buf("dreg", (rows, self.net.pose_pred.cout_p))
+        dreg.zero_()
+        self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.storage(net.scales, "grads"))
+        net.backward(dcls, dreg)
+        from ..libs import distributed as D
+        if D.get_world_size() > 1:
+            D.allreduce_mean_(st.grads[:st.n_train])

@@ -34,6 +34,41 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----------
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """-> list of (kind, algorithmic_flops, milliseconds) for every bracketed launch."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(k, f, e0.elapsed_time(e1)) for (k, f, e0, e1) in rec]
+
+
+class _Timed:
+    __slots__ = ("kind", "flops", "e0")
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops, self.e0 = kind, flops, None
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _prof.append((self.kind, self.flops, self.e0, e1))
+
+
 class Geom:
     """Forward-sense geometry of one conv layer over 1..5 pyramid levels."""
 
@@ -62,7 +97,7 @@ class Geom:
 
 
 def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE, residual=None,
-               seg_scale=None, out_f32=False):
+               seg_scale=None, out_f32=False, flops=0):
     assert x.shape == (geom.rows_in, geom.cin), (x.shape, geom.rows_in, geom.cin)
     assert w.dtype == x.dtype and w.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     odt = torch.float32 if out_f32 else x.dtype
@@ -74,30 +109,33 @@ def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE,
     for v in (ch_scale, ch_shift):
         assert v is None or (v.dtype == torch.float32 and v.numel() >= geom.cout)
     assert seg_scale is None or (seg_scale.dtype == torch.float32 and seg_scale.numel() >= len(geom.levels_in))
-    check(lib.kd6d_conv2d_fwd(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(out), _ptr(ch_scale),
-                              _ptr(ch_shift), act, _ptr(residual), _ptr(seg_scale), int(out_f32),
-                              _stream()), "kd6d_conv2d_fwd")
+    with _Timed("conv_fwd", flops):
+        check(lib.kd6d_conv2d_fwd(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(out), _ptr(ch_scale),
+                                  _ptr(ch_shift), act, _ptr(residual), _ptr(seg_scale), int(out_f32),
+                                  _stream()), "kd6d_conv2d_fwd")
     return out
 
 
-def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False):
+def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     assert dy.shape == (geom.rows_out, geom.cout), (dy.shape, geom.rows_out, geom.cout)
     assert wt.dtype == dy.dtype and wt.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     if dx is None:
         assert not accumulate
         dx = torch.empty((geom.rows_in, geom.cin), dtype=dy.dtype, device=dy.device)
     assert dx.shape == (geom.rows_in, geom.cin) and dx.dtype == dy.dtype
-    check(lib.kd6d_conv2d_dgrad(geom.ref, dt_code(dy.dtype), _ptr(dy), _ptr(wt), _ptr(dx),
-                                int(accumulate), _stream()), "kd6d_conv2d_dgrad")
+    with _Timed("conv_dgrad", flops):
+        check(lib.kd6d_conv2d_dgrad(geom.ref, dt_code(dy.dtype), _ptr(dy), _ptr(wt), _ptr(dx),
+                                    int(accumulate), _stream()), "kd6d_conv2d_dgrad")
     return dx
 
 
-def conv2d_wgrad(geom, x, dy, dw):
+def conv2d_wgrad(geom, x, dy, dw, flops=0):
     assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
     assert x.dtype == dy.dtype and dw.dtype == torch.float32
     assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
-    check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _stream()),
-          "kd6d_conv2d_wgrad")
+    with _Timed("conv_wgrad", flops):
+        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _stream()),
+              "kd6d_conv2d_wgrad")
     return dw
 
 
@@ -112,10 +150,15 @@ def colstats(x, sum_, sumsq=None):
           "kd6d_colstats")
 
 
+def _xf32(x, act_dtype):
+    """1 when the pre-normalisation tensor is fp32 but activations are bf16."""
+    return int(x.dtype == torch.float32 and act_dtype == torch.bfloat16)
+
+
 def bn_train_fwd(x, y, sum_, sumsq, gamma, beta, eps, momentum, running_mean, running_var,
                  save_mean, save_invstd, act):
     rows, c = x.shape
-    check(lib.kd6d_bn_train_fwd(dt_code(x.dtype), _ptr(x), _ptr(y), rows, c, _ptr(sum_), _ptr(sumsq),
+    check(lib.kd6d_bn_train_fwd(dt_code(y.dtype), _xf32(x, y.dtype), _ptr(x), _ptr(y), rows, c, _ptr(sum_), _ptr(sumsq),
                                 _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
                                 _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), act, _stream()),
           "kd6d_bn_train_fwd")
@@ -124,11 +167,12 @@ def bn_train_fwd(x, y, sum_, sumsq, gamma, beta, eps, momentum, running_mean, ru
 
 def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta):
     rows, c = x.shape
-    code = dt_code(x.dtype)
-    check(lib.kd6d_bn_train_bwd_reduce(code, _ptr(x), _ptr(dz), rows, c, _ptr(mean), _ptr(invstd),
+    code = dt_code(dz.dtype)
+    xf = _xf32(x, dz.dtype)
+    check(lib.kd6d_bn_train_bwd_reduce(code, xf, _ptr(x), _ptr(dz), rows, c, _ptr(mean), _ptr(invstd),
                                        _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
                                        _ptr(ws_sum_dy_xhat), _stream()), "kd6d_bn_train_bwd_reduce")
-    check(lib.kd6d_bn_train_bwd_apply(code, _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
+    check(lib.kd6d_bn_train_bwd_apply(code, xf, _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
                                       _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
                                       _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), _stream()),
           "kd6d_bn_train_bwd_apply")
@@ -144,7 +188,7 @@ def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
     assert stats.numel() >= len(level_hw) * batch * groups * 2
-    check(lib.kd6d_gn_relu_fwd(dt_code(x.dtype), _ptr(x), _ptr(y), _hw_array(level_hw), len(level_hw),
+    check(lib.kd6d_gn_relu_fwd(dt_code(y.dtype), _xf32(x, y.dtype), _ptr(x), _ptr(y), _hw_array(level_hw), len(level_hw),
                                batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats), _stream()),
           "kd6d_gn_relu_fwd")
     return y
@@ -153,7 +197,7 @@ def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats):
 def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
-    check(lib.kd6d_gn_relu_bwd(dt_code(x.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
+    check(lib.kd6d_gn_relu_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
                                len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), _ptr(stats),
                                _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), _stream()), "kd6d_gn_relu_bwd")
     return dx
@@ -206,16 +250,17 @@ def image_to_nhwc(img, dtype, cpad=8, out=None):
     return out
 
 
-def sinkhorn_div(xs, alpha, s_off, yt, beta, t_off, n_images, p, blur, scaling, reach):
-    """xs (P,8,2), alpha (P,8), s_off (B+1) int32, yt (M,8,2), beta (M,8), t_off (B+1).
+def sinkhorn_div(xs, alpha, s_start, s_cnt, yt, beta, t_start, t_cnt, n_images, p, blur, scaling, reach):
+    """xs (P,8,2), alpha (P,8), yt (M,8,2), beta (M,8); image b owns student rows
+    [s_start[b], s_start[b]+s_cnt[b]) and teacher rows likewise (int32 device arrays).
     Returns loss_img (B), valid_img (B) int32, grad_xs (P,8,2), grad_alpha (P,8)."""
     dev = xs.device
     loss = torch.empty(n_images, dtype=torch.float32, device=dev)
     valid = torch.empty(n_images, dtype=torch.int32, device=dev)
     gx = torch.zeros_like(xs)
     ga = torch.zeros_like(alpha)
-    check(lib.kd6d_sinkhorn_div_fwd_bwd(_ptr(xs), _ptr(alpha), _ptr(s_off), _ptr(yt), _ptr(beta),
-                                        _ptr(t_off), n_images, p, blur, scaling,
+    check(lib.kd6d_sinkhorn_div_fwd_bwd(_ptr(xs), _ptr(alpha), _ptr(s_start), _ptr(s_cnt), _ptr(yt), _ptr(beta),
+                                        _ptr(t_start), _ptr(t_cnt), n_images, p, blur, scaling,
                                         reach if reach is not None else -1.0, _ptr(loss), _ptr(valid),
                                         _ptr(gx), _ptr(ga), _stream()), "kd6d_sinkhorn_div_fwd_bwd")
     return loss, valid, gx, ga

@@ -1,0 +1,57 @@
+"""Fused clip + AdamW over the flat parameter buffer (train_kd.py:138-139, train_libs.py:119).
+
+Subclasses torch.optim.Optimizer only for bookkeeping (param_groups / lr schedulers such as the
+reference's OneCycleLR work unchanged); step() is two kd6d launches and never touches torch math.
+"""
+import torch
+
+from . import ops
+from .ops import check, lib
+
+
+class FusedClipAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, max_norm=1.0):
+        self.model = model
+        self.net = model.net
+        super().__init__([p for p in model.parameters()], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_norm = max_norm
+        st = self.net.store
+        st.ensure_grads()
+        dev = st.params.device
+        self.exp_avg = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        st = self.net.store
+        g = self.param_groups[0]
+        self.steps += 1
+        n = st.n_train
+        P = ops._ptr
+        s = ops._stream()
+        self.gnorm_sq.zero_()
+        check(lib.kd6d_sumsq(P(st.grads), n, P(self.gnorm_sq), s), "kd6d_sumsq")
+        shadow = st.ensure_shadow() if self.net.dtype == torch.bfloat16 else None
+        check(lib.kd6d_clip_adamw(P(st.params), P(st.grads), P(self.exp_avg), P(self.exp_avg_sq), n, P(self.gnorm_sq),
+                                  float(self.max_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                  float(g["eps"]), float(g["weight_decay"]), self.steps, P(shadow), s), "kd6d_clip_adamw")
+        self.net._weights_dirty = shadow is None and self.net.dtype == torch.bfloat16
+        for _, bn in self.net.bns:
+            bn.fold = None
+
+    def grad_norm(self):
+        """Pre-clip global gradient norm of the last step (device scalar)."""
+        return self.gnorm_sq.sqrt()
+
+    def state_dict(self):
+        return dict(steps=self.steps, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(),
+                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd["steps"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)

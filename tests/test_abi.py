@@ -1,0 +1,49 @@
+"""CPU: libkd6d.so loads and exports every symbol include/kd6d.h declares; argument checks of the
+C ABI reject bad input before touching a device (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "kd6d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kd6d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from kd6d import _lib
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), "libkd6d.so does not export %s" % n
+    bound = set(_lib.SIGNATURES) | {"kd6d_last_error"}
+    assert set(names) <= bound, "header symbols without a ctypes binding: %s" % sorted(set(names) - bound)
+    assert bound <= set(names), "bindings without a header declaration: %s" % sorted(bound - set(names))
+    assert _lib.lib.kd6d_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_checks_fail_loudly_without_gpu():
+    from kd6d import _lib
+    lib = _lib.lib
+    g = _lib.ConvGeom()
+    g.nseg, g.batch, g.cin, g.cout, g.ksize, g.stride, g.pad = 1, 1, 12, 16, 3, 1, 1   # cin % 8 != 0
+    g.seg[0].in_h = g.seg[0].in_w = g.seg[0].out_h = g.seg[0].out_w = 4
+    rc = lib.kd6d_conv2d_fwd(ctypes.byref(g), _lib.KD6D_BF16, None, None, None, None, None, 0, None, None, 0, None)
+    assert rc == -1 and b"cin=12" in lib.kd6d_last_error()
+    g.cin = 16
+    rc = lib.kd6d_conv2d_fwd(ctypes.byref(g), _lib.KD6D_BF16, None, None, None, None, None, 0, None, None, 0, None)
+    assert rc == -1 and b"null tensor" in lib.kd6d_last_error()
+    g.seg[0].out_h = 5
+    rc = lib.kd6d_conv2d_dgrad(ctypes.byref(g), _lib.KD6D_F32, None, None, None, 0, None)
+    assert rc == -1 and b"inconsistent" in lib.kd6d_last_error()
+    rc = lib.kd6d_sinkhorn_div_fwd_bwd(*([None] * 8), 4, 1.0, 0.001, 0.5, 0.5, *([None] * 5))
+    assert rc == -1
+    try:
+        _lib.check(rc, "kd6d_sinkhorn_div_fwd_bwd")
+        raise AssertionError("check() must raise")
+    except _lib.Kd6dError as e:
+        assert "null pointer" in str(e)
+    assert lib.kd6d_sinkhorn_max_points() >= 64

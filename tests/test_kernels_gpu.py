@@ -171,13 +171,16 @@ def test_pack_dgrad_weights(gpu_device):
             off += n
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+MIXED = [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, False)]   # (activation dtype, x kept fp32)
+
+
+@pytest.mark.parametrize("dtype,xf32", MIXED)
 @pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64)])
-def test_batchnorm_train_fwd_bwd(gpu_device, dtype, C, rows):
+def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows):
     ops = _ops()
     dev = gpu_device
     g = torch.Generator().manual_seed(C + rows)
-    x = round_to(torch.randn(rows, C, generator=g) * 2 + 0.5, dtype)
+    x = round_to(torch.randn(rows, C, generator=g) * 2 + 0.5, torch.float32 if xf32 else dtype)
     dz = round_to(torch.randn(rows, C, generator=g), dtype)
     gamma = torch.rand(C, generator=g) + 0.5
     beta = torch.randn(C, generator=g) * 0.1
@@ -189,14 +192,14 @@ def test_batchnorm_train_fwd_bwd(gpu_device, dtype, C, rows):
     rmr, rvr = rm.double().clone(), rv.double().clone()
     yr = F.leaky_relu(F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5), 0.1)
     yr.backward(dz.double())
-    xd, dzd = x.to(dtype).to(dev), dz.to(dtype).to(dev)
+    xd, dzd = x.to(torch.float32 if xf32 else dtype).to(dev), dz.to(dtype).to(dev)
     s1 = torch.zeros(C, device=dev); s2 = torch.zeros(C, device=dev)
     ops.colstats(xd, s1, s2)
-    y = torch.empty_like(xd)
+    y = torch.empty_like(dzd)
     rm_d, rv_d = rm.to(dev), rv.to(dev)
     mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
     ops.bn_train_fwd(xd, y, s1, s2, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm_d, rv_d, mean, invstd, 1)
-    dx = torch.empty_like(xd)
+    dx = torch.empty_like(dzd)
     w1 = torch.zeros(C, device=dev); w2 = torch.zeros(C, device=dev)
     dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
     ops.bn_train_bwd(xd, dzd, dx, mean, invstd, gamma.to(dev), beta.to(dev), 1, w1, w2, dgam, dbet)
@@ -212,13 +215,27 @@ def test_batchnorm_train_fwd_bwd(gpu_device, dtype, C, rows):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,rows", [(240, 1003), (16, 50), (40, 333)])
+def test_colstats_any_channel_count(gpu_device, dtype, C, rows):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    x = round_to(torch.randn(rows, C, generator=g), dtype)
+    s1 = torch.zeros(C, device=gpu_device); s2 = torch.zeros(C, device=gpu_device)
+    ops.colstats(x.to(dtype).to(gpu_device), s1, s2)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(s1.cpu(), x.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(s2.cpu(), (x * x).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype,xf32", MIXED)
 @pytest.mark.parametrize("C", [128, 256])
-def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, C):
+def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C):
     ops = _ops()
     dev = gpu_device
     B, G, levels = 3, 32, [(6, 6), (3, 3), (2, 2), (1, 1)]
     g = torch.Generator().manual_seed(C)
-    xs = [round_to(torch.randn(B, C, h, w, generator=g) * 1.5 + 0.2, dtype) for (h, w) in levels]
+    xdt = torch.float32 if xf32 else dtype
+    xs = [round_to(torch.randn(B, C, h, w, generator=g) * 1.5 + 0.2, xdt) for (h, w) in levels]
     dzs = [round_to(torch.randn(B, C, h, w, generator=g), dtype) for (h, w) in levels]
     gamma = torch.rand(C, generator=g) + 0.5
     beta = torch.randn(C, generator=g) * 0.2
@@ -231,8 +248,8 @@ def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, C):
         yr.backward(dz.double())
         refs.append(yr.detach()); xrs.append(xr)
     hw = [h * w for (h, w) in levels]
-    xp = pack_levels(xs, dtype).to(dev); dzp = pack_levels(dzs, dtype).to(dev)
-    y = torch.empty_like(xp); dx = torch.empty_like(xp)
+    xp = pack_levels(xs, xdt).to(dev); dzp = pack_levels(dzs, dtype).to(dev)
+    y = torch.empty_like(dzp); dx = torch.empty_like(dzp)
     stats = torch.empty(len(levels) * B * G * 2, device=dev)
     gsum = torch.empty_like(stats)
     dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
@@ -328,8 +345,9 @@ def test_sinkhorn_kernel_vs_oracle(gpu_device, reach):
                                                  blur=blur, scaling=0.5, reach=reach)
     dev = gpu_device
     t = lambda a: torch.from_numpy(a).to(dev)
-    loss, valid, gx, ga = ops.sinkhorn_div(t(xs), t(al), t(s_off), t(yt), t(be), t(t_off), len(counts_s),
-                                           2.0, blur, 0.5, reach)
+    loss, valid, gx, ga = ops.sinkhorn_div(t(xs), t(al), t(s_off[:-1].copy()), t(np.asarray(counts_s, np.int32)),
+                                           t(yt), t(be), t(t_off[:-1].copy()), t(np.asarray(counts_t, np.int32)),
+                                           len(counts_s), 2.0, blur, 0.5, reach)
     torch.cuda.synchronize()
     assert valid.cpu().tolist() == valid_r.tolist()
     np.testing.assert_allclose(loss.cpu().numpy(), loss_r, rtol=1e-4, atol=1e-7)

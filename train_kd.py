@@ -1,0 +1,121 @@
+"""KD training entry point -- same command line, config surface and loop as the reference's
+train_kd.py:34-171, on the MI355X-native kd6d step.
+
+    python train_kd.py --config_file ./configs/ape.yaml --config_file_t ./configs/ape.yaml \
+        --backbone darknet_tiny_h --backbone_t darknet53 --weight_file_t model_t_ape/final.pth \
+        --kd_weight 5. --max_iters 10000 --working_dir outputs/ape/kd/ --synthetic
+
+Multi-GPU: python -m torch.distributed.run --nproc-per-node N train_kd.py ...  (one process per
+GPU, backend nccl = RCCL).  The BOP/LINEMOD reader and the evaluation path of the reference are
+outside the hot path; without --synthetic this script stops with a clear message.
+"""
+import json
+import os
+import random
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "kd-6d-pose-adlp_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from kd6d.arguments.argument_kd import get_args  # noqa: E402
+from kd6d.kd_losses import PackedTargets  # noqa: E402
+from kd6d.libs.distributed import get_rank, shard_batch, synchronize  # noqa: E402
+from kd6d.libs.poses import ImageList  # noqa: E402
+from kd6d.libs.train_libs import build_model, build_model_teacher  # noqa: E402
+from kd6d.models.model_kd import PoseModuleKD as PoseModule  # noqa: E402
+from kd6d.synthetic import make_batch  # noqa: E402
+
+
+def synthetic_loader(cfg, device, n_batches=8):
+    per_gpu = shard_batch(cfg["SOLVER"]["IMS_PER_BATCH"])
+    size = cfg["RUNTIME"].get("IMAGE_SIZE", 256)
+    batches = []
+    for i in range(n_batches):
+        images, targets = make_batch(per_gpu, 1000 * get_rank() + i, crop=size)
+        batches.append((images.to(device), PackedTargets(targets, device), None))
+    while True:
+        for b in batches:
+            yield b
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    np.random.seed(0)
+    random.seed(0)
+    cfg, cfg_t = get_args()
+
+    n_gpu = int(os.environ["WORLD_SIZE"]) if "WORLD_SIZE" in os.environ else 1
+    local_rank = int(os.environ.get("LOCAL_RANK", cfg["RUNTIME"]["LOCAL_RANK"]))
+    cfg["RUNTIME"]["N_GPU"] = n_gpu
+    cfg["RUNTIME"]["DISTRIBUTED"] = n_gpu > 1
+    cfg_t["RUNTIME"]["DISTRIBUTED"] = n_gpu > 1
+    device = cfg["RUNTIME"]["RUNNING_DEVICE"]
+    if device != "cuda":
+        raise SystemExit("the kd6d step runs on MI355X only (--running_device cuda); the CPU restatement "
+                         "lives in oracle/ and is test infrastructure")
+    torch.cuda.set_device(local_rank)
+    if cfg["RUNTIME"]["DISTRIBUTED"]:
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+        synchronize()
+
+    if not cfg["RUNTIME"]["SYNTHETIC"]:
+        raise SystemExit("the BOP/LINEMOD reader is outside the KD-step hot path (SURVEY.md 8(f)-4); "
+                         "run with --synthetic")
+    train_loader = synthetic_loader(cfg, device)
+    cfg["KD"]["vis_dir"] = cfg["RUNTIME"]["WORKING_DIR"]
+
+    print("Building teacher ......")
+    model_t = build_model_teacher(cfg_t, PoseModule, device)
+    print("Building student ......")
+    model, optimizer, scheduler, total_steps = build_model(cfg, PoseModule, device)
+    VAL_FREQ = cfg["SOLVER"]["VAL_FREQ"]
+    wd = cfg["RUNTIME"]["WORKING_DIR"]
+    print("working directory: " + wd)
+    if get_rank() == 0:
+        os.makedirs(wd, exist_ok=True)
+        print("Model size: Student VS Teacher: %d  vs %d" % (sum(p.numel() for p in model.parameters()),
+                                                           sum(p.numel() for p in model_t.parameters())))
+        with open(os.path.join(wd, "cfg.json"), "w") as f:
+            json.dump(cfg, f, indent=4, sort_keys=True, default=str)
+
+    model.train()
+    model_t.eval()
+    cfg_kd = cfg["KD"]
+    w_cls, w_reg, w_kd = cfg["SOLVER"]["LOSS_WEIGHT_CLS"], cfg["SOLVER"]["LOSS_WEIGHT_REG"], cfg["KD"]["LOSS_WEIGHT_KD"]
+    t0 = time.time()
+    for idx, (images, targets, _) in enumerate(train_loader):
+        if total_steps >= cfg["SOLVER"]["MAX_ITER"]:
+            if get_rank() == 0:
+                torch.save(model.state_dict(), os.path.join(wd, "final.pth"))
+            print("Training finished")
+            break
+        total_steps += 1
+        model.zero_grad()
+        with torch.no_grad():
+            pred_t = model_t(images, targets=targets, is_teacher=True, cfg_kd=cfg_kd)
+        _, loss_dict = model(images, targets=targets, pred_t=pred_t, cfg_kd=cfg_kd)
+        loss_cls = (loss_dict["loss_cls"] * w_cls).mean()
+        loss_reg = (loss_dict["loss_reg"] * w_reg).mean()
+        loss = loss_cls + loss_reg
+        loss_kd = (loss_dict["loss_kd"] * w_kd).mean()
+        if w_kd > 0.0:
+            loss = loss + loss_kd
+        loss.backward()
+        optimizer.step()          # clip_grad_norm_(GRAD_CLIP) is fused into the optimiser kernel
+        scheduler.step()
+        if get_rank() == 0 and (total_steps % 50 == 0 or total_steps == 1):
+            dt = time.time() - t0
+            print("steps: %d/%d, lr:%.6f, cls:%.4f, reg:%.4f, kd:%.4f  (%.1f img/s)" % (
+                total_steps, cfg["SOLVER"]["MAX_ITER"], optimizer.param_groups[0]["lr"], float(loss_cls),
+                float(loss_reg), float(loss_kd), idx * cfg["SOLVER"]["IMS_PER_BATCH"] / max(dt, 1e-9)))
+        if get_rank() == 0 and total_steps % VAL_FREQ == 0:
+            torch.save({"steps": total_steps, "model": model.state_dict(), "optim": optimizer.state_dict(),
+                        "sched": scheduler.state_dict()}, os.path.join(wd, "latest.pth"))
+    if get_rank() == 0:
+        with open(os.path.join(wd, "info.txt"), "w") as f:
+            f.write("finished at: %s\nworking_dir: %s\ncommands:%s" % (
+                time.strftime("%Y%m%d_%H%M%S"), wd, " ".join(sys.argv)))
