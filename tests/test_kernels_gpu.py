@@ -354,3 +354,46 @@ def test_sinkhorn_kernel_vs_oracle(gpu_device, reach):
     gscale = np.abs(gx_r).max()
     np.testing.assert_allclose(gx.cpu().numpy(), gx_r, rtol=2e-3, atol=2e-3 * gscale)
     np.testing.assert_allclose(ga.cpu().numpy(), ga_r, rtol=2e-3, atol=2e-3 * np.abs(ga_r).max())
+
+
+def test_fused_clip_adamw_matches_torch(gpu_device):
+    """kd6d_sumsq + kd6d_clip_adamw vs clip_grad_norm_ + torch.optim.AdamW (train_libs.py:119 settings)
+    over several steps on identical gradients, and vs the reference capture tests/golden/optim.npz."""
+    import ctypes
+    import os
+    ops = _ops()
+    lib, P = ops.lib, ops._ptr
+    dev = gpu_device
+    n = 10007
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, weight_decay=1e-4, eps=1e-8)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 10100, pct_start=0.05, cycle_momentum=False,
+                                              anneal_strategy="linear")
+    p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    shadow = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (10.0 if step % 2 else 0.001)    # clipped and unclipped steps
+        ref_p.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        lr = opt.param_groups[0]["lr"]
+        opt.step(); sch.step()
+        gd = grad.to(dev)
+        ss = torch.zeros(1, device=dev)
+        ops.check(lib.kd6d_sumsq(P(gd), n, P(ss), ops._stream()))
+        ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(ss), 1.0, lr, 0.9, 0.999, 1e-8, 1e-4, step,
+                                      P(shadow), ops._stream()))
+        torch.cuda.synchronize()
+        assert float(ss) == pytest.approx(float((grad.double() ** 2).sum()), rel=1e-5)
+        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim.npz"))
+    p = torch.linspace(-1, 1, 16).to(dev); m = torch.zeros(16, device=dev); v = torch.zeros(16, device=dev)
+    g = torch.Generator().manual_seed(1)
+    for it in range(3):
+        gd = torch.randn(16, generator=g).to(dev)
+        ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), 16, None, 0.0, float(z["lrs"][it]), 0.9, 0.999, 1e-8,
+                                      1e-4, it + 1, None, ops._stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p.cpu().numpy(), z["params"][it], rtol=1e-5, atol=1e-7)
