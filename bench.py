@@ -49,7 +49,9 @@ def parse():
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--frame", type=str, default="crop256", choices=["crop256", "full640"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--cpu-steps", type=int, default=4)
+    p.add_argument("--layer-table", type=str, default="", help="write the per-launch conv table (instrumented steps) here")
     return p.parse_args()
 
 
@@ -117,8 +119,16 @@ def main():
         images, targets = make_batch(B, 1000 * rank + i, full_frame=full)
         batches.append((images.to(dev), PackedTargets(targets, dev)))
 
-    def step(i):
+    from kd6d.graph import GraphedKDStep
+    gstep = None if args.no_graph else GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0))
+
+    def step(i, eager=False):
         images, tgt = batches[i % len(batches)]
+        if gstep is not None and not eager:
+            ld = gstep(images, tgt)
+            sched.step()
+            return ld
+        student._defer_allreduce = False
         student.zero_grad()
         with torch.no_grad():
             pred_t = teacher(images, targets=tgt, is_teacher=True)
@@ -137,6 +147,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ld = step(args.warmup + i)
+    t_enqueued = time.perf_counter() - t0          # host-side launch time (the GPU runs behind)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -154,16 +165,18 @@ def main():
     if rank == 0:
         ops.profile_begin()
     for i in range(n_instr):
-        step(args.warmup + args.steps + i)
+        step(args.warmup + args.steps + i, eager=True)
     rec = ops.profile_end() if rank == 0 else []
 
     out = None
+    if rank == 0 and args.layer_table:
+        write_layer_table(args.layer_table, rec, n_instr)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         size = 640 if full else 256
         flop_img = FLOP_PER_IMG.get((args.student, size))
-        conv = [(k, f, ms_) for (k, f, ms_) in rec if k.startswith("conv")]
+        conv = [(k, f, ms_) for (k, f, ms_, _t) in rec if k.startswith("conv")]
         tot_flop = sum(f for _, f, _ in conv)
         tot_ms = sum(m for _, _, m in conv)
         by_kind = {}
@@ -188,8 +201,10 @@ def main():
                                       "%s" % (args.student, args.precision, B,
                                               "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
                           "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "launch": "eager" if gstep is None else "hipGraph replay (2 graphs/step)",
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
-               "losses_last_step": losses, "finite": finite, "roofline": roof}
+               "losses_last_step": losses, "finite": finite, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+               "roofline": roof}
         # ---- CPU baseline leg (oracle = port of the reference step), rank 0, N=1 only ----
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, B, full)
@@ -198,6 +213,22 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def write_layer_table(path, rec, n_instr):
+    """Per-launch conv table of one step (mean over the instrumented steps), in launch order."""
+    conv = [r for r in rec if r[0].startswith("conv")]
+    per = len(conv) // n_instr
+    lines = ["| # | kind | M | N(cout) | K | k | s | levels | GFLOP | us | TFLOP/s |", "|---|---|---|---|---|---|---|---|---|---|---|"]
+    for i in range(per):
+        k, f, _, g = conv[i]
+        us = 1e3 * sum(conv[i + j * per][2] for j in range(n_instr)) / n_instr
+        m = g.rows_in if k == "conv_dgrad" else g.rows_out
+        lines.append("| %d | %s | %d | %d | %d | %d | %d | %d | %.2f | %.1f | %.0f |" %
+                     (i, k[5:], m, g.cout, g.ksize * g.ksize * g.cin, g.ksize, g.stride, len(g.levels_in), f / 1e9, us,
+                      f / (us * 1e-6) / 1e12 if us > 0 else 0))
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
 
 
 def cpu_baseline(args, B, full):

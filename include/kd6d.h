@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 1
+#define KD6D_ABI_VERSION 2
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -131,12 +131,14 @@ int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz,
 
 /* GroupNorm(groups)+ReLU of the PoseHead towers (models/model.py:395-417) over a multi-level
  * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 floats per
- * (level, image, group) = {mean, rstd}; gsum_ws: workspace of the same size. */
+ * (level, image, group) = RAW sums {sum x, sum x^2} (mean/rstd are derived by the consumers, which is
+ * why the backward takes eps too); gsum_ws: workspace of the same size.  Both are zeroed by the call
+ * (a memset node on `stream`).  Requires C/groups >= granule/2 (a 16-B granule spans <= 2 groups). */
 int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host, int nseg, int batch,
                      int C, int groups, const float* gamma, const float* beta, float eps, float* stats,
                      void* stream);
 int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, const int32_t* level_hw_host,
-                     int nseg, int batch, int C, int groups, const float* gamma, const float* beta,
+                     int nseg, int batch, int C, int groups, const float* gamma, const float* beta, float eps,
                      const float* stats, float* gsum_ws, float* dgamma, float* dbeta, void* stream);
 
 /* MaxPool2d(2,2) (backbone/darknet.py:94-97), nearest-x2 upsample + add (models/model.py:75-78)
@@ -212,11 +214,16 @@ int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const float* cls, c
 /* ---- optimiser: replaces clip_grad_norm_ + AdamW.step of train_kd.py:138-139 on one flat buffer.
  * kd6d_sumsq accumulates sum(x^2) into *out (pre-zeroed); kd6d_clip_adamw applies
  * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update
- * (torch.optim.AdamW semantics, step counted from 1) and refreshes the bf16 shadow if given. */
+ * (torch.optim.AdamW semantics, step counted from 1) and refreshes the bf16 shadow if given.
+ * hyper_dev (optional, 4 floats on the device: lr, 1-beta1^t, sqrt(1-beta2^t), pad) overrides lr/step:
+ * it lets the launch sit inside a captured hipGraph while the OneCycle schedule of
+ * libs/train_libs.py:120 keeps advancing on the host; kd6d_set_hyper writes it (values travel in
+ * the kernel arguments, so the host may run ahead of the device). */
 int kd6d_sumsq(const float* x, int64_t n, float* out, void* stream);
 int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                     const float* gnorm_sq, double max_norm, double lr, double beta1, double beta2, double eps,
-                    double weight_decay, int64_t step, void* bf16_shadow, void* stream);
+                    double weight_decay, int64_t step, const float* hyper_dev, void* bf16_shadow, void* stream);
+int kd6d_set_hyper(float* hyper_dev, double lr, double beta1, double beta2, int64_t step, void* stream);
 int kd6d_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -18,6 +18,9 @@
 //   bf16: v_mfma_f32_16x16x32_bf16, one granule per lane per 32-deep chunk.
 //   fp32: v_mfma_f32_16x16x4_f32 x8 on a 32-deep chunk; lane group q holds
 //         k = 8q..8q+7 (two granules) and MFMA j contracts {8q+j}: exact fp32.
+#include <math.h>
+#include <stdlib.h>
+
 #include "kd6d_common.h"
 
 namespace {
@@ -587,6 +590,191 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Weight gradient, bf16, transposed-read form (the one the step uses).
+//
+// dW[n][j] = sum_m dY[m][n] * im2col(X)[m][j] contracts over pixels m, the slow axis of both NHWC
+// operands.  Tiles are therefore staged in their NATURAL layout -- row = pixel, 256-B pitch, 16-B
+// chunks swizzled by ch ^ (((row&3)<<2) | ((row>>2)&3)) -- with plain 16-B LDS stores, and the MFMA
+// fragments (8 consecutive pixels of one channel per lane) come out of ds_read_b64_tr_b16, the
+// gfx950 transposing LDS read: conflict-free for the two 4-row blocks a 32-lane half fetches.
+// Split over pixel ranges; partial tiles are re-laid out through LDS so every atomic wave-instruction
+// adds 256 contiguous bytes of one dW row.  The split count balances the k-loop against the
+// ~1.3 TB/s fp32-atomic rate of the memory side (launch_wgrad_tr).
+// ---------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tr_off(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int cb, int kc, int g, int q, int pp) {
+  const int r0 = kc * 32 + 8 * g + q;
+  const int ch = 2 * cb + (pp >> 1);
+  const int sub = 8 * (pp & 1);
+  typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + tr_off(r0, ch) + sub));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + tr_off(r0 + 4, ch) + sub));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int BN, int WN, int WJ>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p) {
+  constexpr int BJ = 128, BKM = 64;
+  constexpr int NI = BN / WN / 16;
+  constexpr int JI = BJ / WJ / 16;
+  constexpr int GN = BN / 8, GJ = BJ / 8;   // 16-B granules per tile row
+  constexpr int LN = (GN + 3) / 4, LJ = GJ / 4;
+  constexpr int TILE = BKM * 256;
+  constexpr int EP = BJ + 4;                // fp32 pitch of the epilogue image
+  static_assert(WN * WJ == 4 && NI >= 1 && JI >= 1, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave % WN;
+  const int wj = wave / WN;
+
+  const int tile_j = blockIdx.x % p.n_jtiles;
+  const int tile_n = blockIdx.x / p.n_jtiles;
+  const int n0 = tile_n * BN;
+  const int j0 = tile_j * BJ;
+  const int m_lo = blockIdx.y * p.m_chunk;
+  int m_hi = m_lo + p.m_chunk;
+  if (m_hi > p.M) m_hi = p.M;
+  const int nsteps = (m_hi - m_lo + BKM - 1) / BKM;
+  if (nsteps <= 0) return;
+
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(p.dy);
+
+  // loader: thread -> pixel row tid>>2 of the k-step, granules (tid&3) + 4*i of that row
+  const int prow = tid >> 2, sub = tid & 3;
+  int jcc[LJ], jky[LJ], jkx[LJ];
+  bool jok[LJ];
+#pragma unroll
+  for (int i = 0; i < LJ; ++i) {
+    const int j = j0 + (sub + 4 * i) * 8;
+    jok[i] = j < p.J;
+    const int tap = j / p.Cin;
+    jcc[i] = j - tap * p.Cin;
+    jky[i] = tap / p.ks;
+    jkx[i] = tap - jky[i] * p.ks;
+  }
+  bool nok[LN];
+#pragma unroll
+  for (int i = 0; i < LN; ++i) nok[i] = (sub + 4 * i < GN) && (n0 + (sub + 4 * i) * 8 < p.Cout);
+
+  u32x4_t nreg[LN], jreg[LJ];
+
+  auto issue_loads = [&](int mstep) {
+    const int m = mstep + prow;
+    const bool mv = m < m_hi;
+    // pixel decode (level, image, y, x) once per k-step
+    int mb = 0, hw = 1, dw = 1, sh = 0, sw = 0, s0 = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) {
+      if (s < p.nseg && m >= p.seg[s].m_begin) {
+        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; dw = p.seg[s].dst_w;
+        sh = p.seg[s].src_h; sw = p.seg[s].src_w; s0 = p.seg[s].src_row0;
+      }
+    }
+    const int local = m - mb;
+    const int b = local / hw;
+    const int rem = local - b * hw;
+    const int y = rem / dw;
+    const int xq = rem - y * dw;
+    const int sbase = s0 + b * sh * sw;
+    const int by = y * p.stride - p.pad, bx = xq * p.stride - p.pad;
+#pragma unroll
+    for (int i = 0; i < LN; ++i) {
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (mv && nok[i])
+        v = *reinterpret_cast<const u32x4_t*>(dy + (size_t)m * (size_t)p.Cout + (size_t)(n0 + (sub + 4 * i) * 8));
+      nreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < LJ; ++i) {
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      const int sy = by + jky[i], sx = bx + jkx[i];
+      if (mv && jok[i] && (unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw)
+        v = *reinterpret_cast<const u32x4_t*>(x + (size_t)(sbase + sy * sw + sx) * (size_t)p.Cin + (size_t)jcc[i]);
+      jreg[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    char* ntile = smem + buf * 2 * TILE;
+    char* jtile = ntile + TILE;
+#pragma unroll
+    for (int i = 0; i < LN; ++i)
+      if (sub + 4 * i < GN) *reinterpret_cast<u32x4_t*>(ntile + tr_off(prow, sub + 4 * i)) = nreg[i];
+#pragma unroll
+    for (int i = 0; i < LJ; ++i) *reinterpret_cast<u32x4_t*>(jtile + tr_off(prow, sub + 4 * i)) = jreg[i];
+  };
+
+  f32x4_t acc[NI][JI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < JI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tq = fr >> 2, tp = fr & 3;
+
+  issue_loads(m_lo);
+  store_tiles(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) issue_loads(m_lo + (st + 1) * BKM);
+    const char* ntile = smem + buf * 2 * TILE;
+    const char* jtile = ntile + TILE;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      bf16x8_t fa[NI], fb[JI];
+#pragma unroll
+      for (int a = 0; a < NI; ++a) fa[a] = tr_frag(ntile, wn * (BN / WN / 16) + a, kc, fq, tq, tp);
+#pragma unroll
+      for (int b = 0; b < JI; ++b) fb[b] = tr_frag(jtile, wj * (BJ / WJ / 16) + b, kc, fq, tq, tp);
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < JI; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: [n][j] fp32 image in LDS, then 256-B contiguous atomic rows ----
+  float* et = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < JI; ++b) {
+      const int nl = wn * (BN / WN) + a * 16 + fq * 4;
+      const int jl = wj * (BJ / WJ) + b * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) et[(nl + r) * EP + jl] = acc[a][b][r];
+    }
+  __syncthreads();
+  for (int nl = wave; nl < BN; nl += 4) {
+    const int n = n0 + nl;
+    if (n >= p.Cout) break;
+#pragma unroll
+    for (int h = 0; h < BJ / 64; ++h) {
+      const int jl = h * 64 + lane;
+      const int j = j0 + jl;
+      if (j < p.J) atomicAdd(p.dw + (size_t)n * (size_t)p.J + (size_t)j, et[nl * EP + jl]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // dgrad weight packing: wt[ci][ky][kx][co] <- w[co][ky][kx][ci], all layers at once.
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -719,6 +907,49 @@ void launch_wgrad(const WgradParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, st, q);
 }
 
+template <int BN, int WN, int WJ>
+void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
+  constexpr int BJ = 128, BKM = 64;
+  WgradParams q = p;
+  q.n_jtiles = (p.J + BJ - 1) / BJ;
+  const int ntiles = (p.Cout + BN - 1) / BN;
+  const int tiles = q.n_jtiles * ntiles;
+  const int steps_total = (p.M + BKM - 1) / BKM;
+  // time ~ (steps/S) * t_step + S * |dW| / (fp32 atomic rate 1.3 TB/s), t_step ~ 1.6 us measured
+  //   => S* = sqrt(steps * t_step * rate / |dW|); at most 2 workgroups per CU, because many
+  //   workgroups adding into one small dW are contention-bound (measured: 2048 -> 512 = -25 %)
+  static const double scale = []() {
+    const char* e = getenv("KD6D_WGRAD_SPLIT_SCALE");
+    return e ? atof(e) : 1.0;
+  }();
+  const double dw_bytes = (double)p.Cout * (double)p.J * 4.0;
+  int splits = (int)(scale * sqrt((double)steps_total * 2.08e6 / dw_bytes) + 0.5);
+  if (splits > 512 / tiles) splits = 512 / tiles;
+  if (splits > steps_total / 2) splits = steps_total / 2;
+  if (splits < 1) splits = 1;
+  const int steps_per = (steps_total + splits - 1) / splits;
+  q.m_chunk = steps_per * BKM;
+  splits = (p.M + q.m_chunk - 1) / q.m_chunk;
+  const size_t stage = (size_t)2 * 2 * BKM * 256;
+  const size_t epi = (size_t)BN * (BJ + 4) * 4;
+  const size_t lds = stage > epi ? stage : epi;
+  auto kern = conv_wgrad_tr_kernel<BN, WN, WJ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, st, q);
+}
+
+void dispatch_wgrad_tr(const WgradParams& p, hipStream_t st) {
+  if (p.Cout <= 16) launch_wgrad_tr<16, 1, 4>(p, st);
+  else if (p.Cout <= 32) launch_wgrad_tr<32, 1, 4>(p, st);
+  else if (p.Cout <= 64) launch_wgrad_tr<64, 1, 4>(p, st);
+  else launch_wgrad_tr<128, 2, 2>(p, st);
+}
+
 template <typename T>
 void dispatch_wgrad(const WgradParams& p, hipStream_t st) {
   if (p.Cout <= 16) launch_wgrad<T, 16, 128, 1, 4>(p, st);
@@ -794,7 +1025,7 @@ extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void*
                    "kd6d_conv2d_wgrad: output levels must be packed back to back");
   p.x = x; p.dy = dy; p.dw = dw;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == KD6D_BF16) dispatch_wgrad<bf16_t>(p, st);
+  if (dtype == KD6D_BF16) dispatch_wgrad_tr(p, st);
   else dispatch_wgrad<float>(p, st);
   KD6D_CHECK_LAUNCH("kd6d_conv2d_wgrad");
   return KD6D_OK;

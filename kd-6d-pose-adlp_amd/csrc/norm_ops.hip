@@ -211,32 +211,56 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// GroupNorm(G) + ReLU over multi-level NHWC tensors.  One workgroup per
-// (level, sample): rows = H*W pixels, C channels, G groups of C/G channels.
+// GroupNorm(G) + ReLU over multi-level NHWC tensors.  Statistics are kept as RAW sums
+// stats[(seg*batch + b)*G + g] = {sum x, sum x^2} (fp32 atomics from row-chunk workgroups,
+// so a 32x32 level is reduced by 16 workgroups instead of one); consumers derive
+// mean = s/n, rstd = rsqrt(max(q/n - mean^2, 0) + eps) with n = H*W*C/G.
 // ---------------------------------------------------------------------------
+constexpr int kGnRows = 64;   // rows of one (level, sample) handled by a reduction workgroup
+
 struct GnGeom {
   int nseg, batch, C, G;
   int row0[KD6D_MAX_SEG];
   int hw[KD6D_MAX_SEG];
+  int nblk;                   // reduction workgroups in all
+  int blk0[KD6D_MAX_SEG];     // first reduction workgroup of the level
+  int cps[KD6D_MAX_SEG];      // reduction workgroups (row chunks) per sample
 };
 
-// stats[(seg*batch + b)*G + g] = {mean, rstd}
-template <typename T, typename TX>
-__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict__ x, GnGeom gm,
-                                                            float eps, float* __restrict__ stats) {
-  constexpr int EG = Granule<T>::N;
-  __shared__ float s_sum[64], s_sq[64];
-  const int seg = blockIdx.x / gm.batch, b = blockIdx.x % gm.batch;
-  int row0 = 0, hw = 0;
+// reduction workgroup -> (seg, b, first row, row count)
+__device__ __forceinline__ void gn_chunk(const GnGeom& gm, int blk, int& seg, int& b, int& r_begin, int& r_cnt) {
+  seg = 0;
+  int b0 = 0, cps = 1, hw = 0, row0 = 0;
 #pragma unroll
   for (int s = 0; s < KD6D_MAX_SEG; ++s)
-    if (s == seg) { row0 = gm.row0[s]; hw = gm.hw[s]; }
+    if (s < gm.nseg && blk >= gm.blk0[s]) { seg = s; b0 = gm.blk0[s]; cps = gm.cps[s]; hw = gm.hw[s]; row0 = gm.row0[s]; }
+  const int local = blk - b0;
+  b = local / cps;
+  const int chunk = local - b * cps;
+  const int lo = chunk * kGnRows;
+  r_cnt = min(kGnRows, hw - lo);
+  r_begin = row0 + b * hw + lo;
+}
+
+__device__ __forceinline__ void gn_mean_rstd(const float* __restrict__ st, float inv_n, float eps, float& mu,
+                                             float& rs) {
+  mu = st[0] * inv_n;
+  rs = rsqrtf(fmaxf(st[1] * inv_n - mu * mu, 0.f) + eps);
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict__ x, GnGeom gm,
+                                                            float* __restrict__ stats) {
+  constexpr int EG = Granule<T>::N;
+  __shared__ float s_sum[64], s_sq[64];
+  int seg, b, r_begin, r_cnt;
+  gn_chunk(gm, blockIdx.x, seg, b, r_begin, r_cnt);
   const int C = gm.C, G = gm.G, cpg = C / G;
   if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
   __syncthreads();
   const int cgs = C / EG;
-  const long long ngran = (long long)hw * cgs;
-  const TX* xb = x + (size_t)(row0 + b * hw) * C;
+  const long long ngran = (long long)r_cnt * cgs;
+  const TX* xb = x + (size_t)r_begin * C;
   const int cg = threadIdx.x % cgs;  // (C/EG) | 256
   // a granule may straddle groups when cpg < EG (C=128,G=32,bf16: 2 groups per granule)
   float a1[EG], a2[EG];
@@ -256,18 +280,15 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict
   }
   __syncthreads();
   if (threadIdx.x < G) {
-    const float n = (float)hw * (float)cpg;
-    const float m = s_sum[threadIdx.x] / n;
-    const float var = fmaxf(s_sq[threadIdx.x] / n - m * m, 0.f);
-    float* o = stats + ((size_t)blockIdx.x * G + threadIdx.x) * 2;
-    o[0] = m;
-    o[1] = rsqrtf(var + eps);
+    float* o = stats + ((size_t)(seg * gm.batch + b) * G + threadIdx.x) * 2;
+    atomicAdd(o, s_sum[threadIdx.x]);
+    atomicAdd(o + 1, s_sq[threadIdx.x]);
   }
 }
 
-__device__ __forceinline__ void gn_locate(const GnGeom& gm, long long row, int& seg, int& b) {
-  seg = 0; b = 0;
-  int r0 = 0, hw = 1;
+__device__ __forceinline__ void gn_locate(const GnGeom& gm, long long row, int& seg, int& b, int& hw) {
+  seg = 0; b = 0; hw = 1;
+  int r0 = 0;
 #pragma unroll
   for (int s = 0; s < KD6D_MAX_SEG; ++s)
     if (s < gm.nseg && row >= gm.row0[s]) { seg = s; r0 = gm.row0[s]; hw = gm.hw[s]; }
@@ -276,7 +297,7 @@ __device__ __forceinline__ void gn_locate(const GnGeom& gm, long long row, int& 
 
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
-    const TX* __restrict__ x, T* __restrict__ y, GnGeom gm, long long ngran,
+    const TX* __restrict__ x, T* __restrict__ y, GnGeom gm, long long ngran, float eps,
     const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta) {
   constexpr int EG = Granule<T>::N;
@@ -289,56 +310,64 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     const long long row = g / cgs;
-    int seg, b;
-    gn_locate(gm, row, seg, b);
+    int seg, b, hw;
+    gn_locate(gm, row, seg, b, hw);
+    const float inv_n = 1.f / ((float)hw * (float)cpg);
     const float* st = stats + ((size_t)(seg * gm.batch + b) * G) * 2;
     float v[EG];
     load_x<TX, EG>(x, g, v);
+    constexpr int NG = 2;                 // a granule touches at most 2 groups (cpg >= EG/2)
+    const int g0 = (cg * EG) / cpg;
+    float mu[NG], rs[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) gn_mean_rstd(st + min(g0 + k, G - 1) * 2, inv_n, eps, mu[k], rs[k]);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
-      const int grp = (cg * EG + e) / cpg;
-      const float t = (v[e] - st[grp * 2]) * st[grp * 2 + 1] * ga[e] + be[e];
+      const int k = (cg * EG + e) / cpg - g0;
+      const float t = (v[e] - (k ? mu[1] : mu[0])) * (k ? rs[1] : rs[0]) * ga[e] + be[e];
       v[e] = fmaxf(t, 0.f);
     }
     yg[g] = f32_to_granule<T>(v);
   }
 }
 
-// backward reduce: one workgroup per (level, sample):
-//   gsum[(seg,b,g)] = {sum(dy*gamma), sum(dy*gamma*xhat)}; dgamma/dbeta via atomics.
+// backward reduce over row chunks:
+//   gsum[(seg,b,g)] += {sum(dy*gamma), sum(dy*gamma*xhat)}; dgamma/dbeta via atomics.
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
-    const TX* __restrict__ x, const T* __restrict__ dz, GnGeom gm, const float* __restrict__ stats,
+    const TX* __restrict__ x, const T* __restrict__ dz, GnGeom gm, float eps, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gsum,
     float* dgamma, float* dbeta) {
   constexpr int EG = Granule<T>::N;
   __shared__ float s_a[64], s_b[64];
   extern __shared__ float red[];  // 2*C
-  const int seg = blockIdx.x / gm.batch, b = blockIdx.x % gm.batch;
-  int row0 = 0, hw = 0;
+  int seg, b, r_begin, r_cnt;
+  gn_chunk(gm, blockIdx.x, seg, b, r_begin, r_cnt);
+  int hw = 1;
 #pragma unroll
   for (int s = 0; s < KD6D_MAX_SEG; ++s)
-    if (s == seg) { row0 = gm.row0[s]; hw = gm.hw[s]; }
+    if (s == seg) hw = gm.hw[s];
   const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
+  const float inv_n = 1.f / ((float)hw * (float)cpg);
   if (threadIdx.x < 64) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
   for (int i = threadIdx.x; i < 2 * C; i += kThreads) red[i] = 0.f;
   __syncthreads();
   const int cg = threadIdx.x % cgs;
-  const float* st = stats + ((size_t)blockIdx.x * G) * 2;
+  const size_t sb = (size_t)(seg * gm.batch + b) * G;
   float ga[EG], be[EG], mu[EG], rs[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     ga[e] = gamma[c]; be[e] = beta[c];
-    mu[e] = st[(c / cpg) * 2]; rs[e] = st[(c / cpg) * 2 + 1];
+    gn_mean_rstd(stats + (sb + c / cpg) * 2, inv_n, eps, mu[e], rs[e]);
   }
   float a_dy[EG], a_dyx[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) { a_dy[e] = 0.f; a_dyx[e] = 0.f; }
-  const size_t base = (size_t)(row0 + b * hw) * C;
+  const size_t base = (size_t)r_begin * C;
   const TX* xb = x + base;
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz + base);
-  const long long ngran = (long long)hw * cgs;
+  const long long ngran = (long long)r_cnt * cgs;
   for (long long g = threadIdx.x; g < ngran; g += kThreads) {
     float xv[EG], dv[EG];
     load_x<TX, EG>(xb, g, xv);
@@ -362,9 +391,9 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
   }
   __syncthreads();
   if (threadIdx.x < G) {
-    float* o = gsum + ((size_t)blockIdx.x * G + threadIdx.x) * 2;
-    o[0] = s_a[threadIdx.x];
-    o[1] = s_b[threadIdx.x];
+    float* o = gsum + (sb + threadIdx.x) * 2;
+    atomicAdd(o, s_a[threadIdx.x]);
+    atomicAdd(o + 1, s_b[threadIdx.x]);
   }
   for (int c = threadIdx.x; c < C; c += kThreads) {
     if (dbeta) atomicAdd(dbeta + c, red[c]);
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm,
-    long long ngran, const float* __restrict__ stats, const float* __restrict__ gsum,
+    long long ngran, float eps, const float* __restrict__ stats, const float* __restrict__ gsum,
     const float* __restrict__ gamma, const float* __restrict__ beta) {
   constexpr int EG = Granule<T>::N;
   const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
@@ -388,25 +417,31 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     const long long row = g / cgs;
-    int seg, b;
-    gn_locate(gm, row, seg, b);
-    int hw = 1;
-#pragma unroll
-    for (int s = 0; s < KD6D_MAX_SEG; ++s)
-      if (s == seg) hw = gm.hw[s];
+    int seg, b, hw;
+    gn_locate(gm, row, seg, b, hw);
     const float inv_n = 1.f / ((float)hw * (float)cpg);
     const size_t sb = (size_t)(seg * gm.batch + b) * G;
     float xv[EG], dv[EG];
     load_x<TX, EG>(x, g, xv);
     granule_to_f32<T>(dg[g], dv);
+    constexpr int NG = 2;
+    const int g0 = (cg * EG) / cpg;
+    float mu[NG], rs[NG], k1[NG], k2[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int gi = min(g0 + k, G - 1);
+      gn_mean_rstd(stats + (sb + gi) * 2, inv_n, eps, mu[k], rs[k]);
+      k1[k] = gsum[(sb + gi) * 2] * inv_n;
+      k2[k] = gsum[(sb + gi) * 2 + 1] * inv_n;
+    }
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
-      const int grp = (cg * EG + e) / cpg;
-      const float mu = stats[(sb + grp) * 2], rs = stats[(sb + grp) * 2 + 1];
-      const float xh = (xv[e] - mu) * rs;
+      const int k = (cg * EG + e) / cpg - g0;
+      const float m_ = k ? mu[1] : mu[0], r_ = k ? rs[1] : rs[0];
+      const float xh = (xv[e] - m_) * r_;
       const float pre = xh * ga[e] + be[e];
       const float d = pre > 0.f ? dv[e] * ga[e] : 0.f;
-      dv[e] = rs * (d - gsum[(sb + grp) * 2] * inv_n - xh * gsum[(sb + grp) * 2 + 1] * inv_n);
+      dv[e] = r_ * (d - (k ? k1[1] : k1[0]) - xh * (k ? k2[1] : k2[0]));
     }
     og[g] = f32_to_granule<T>(dv);
   }
@@ -614,15 +649,20 @@ int check_channels(int dtype, int C, const char* who) {
 bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom* gm) {
   if (nseg < 1 || nseg > KD6D_MAX_SEG || batch < 1 || G < 1 || G > 64 || C % G) return false;
   gm->nseg = nseg; gm->batch = batch; gm->C = C; gm->G = G;
-  int row = 0;
+  int row = 0, blk = 0;
   for (int s = 0; s < KD6D_MAX_SEG; ++s) {
     gm->row0[s] = row;
     gm->hw[s] = s < nseg ? level_hw[s] : 0;
+    gm->blk0[s] = blk;
+    gm->cps[s] = 1;
     if (s < nseg) {
       if (level_hw[s] <= 0) return false;
       row += batch * level_hw[s];
+      gm->cps[s] = (level_hw[s] + kGnRows - 1) / kGnRows;
+      blk += batch * gm->cps[s];
     }
   }
+  gm->nblk = blk;
   return true;
 }
 
@@ -746,11 +786,15 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, co
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
+  KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_fwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
+  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
+    kd6d_set_error("kd6d_gn_relu_fwd: memset failed");
+    return KD6D_ERR_LAUNCH;
+  }
   DISPATCH_TTX(dtype, x_f32, {
-    hipLaunchKernelGGL((gn_stats_kernel<T_, TX_>), dim3(nseg * batch), dim3(kThreads), 0, st, (const TX_*)x, gm,
-                       eps, stats);
+    hipLaunchKernelGGL((gn_stats_kernel<T_, TX_>), dim3(gm.nblk), dim3(kThreads), 0, st, (const TX_*)x, gm, stats);
     hipLaunchKernelGGL((gn_relu_fwd_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x, (T_*)y, gm,
-                       ngran, stats, gamma, beta);
+                       ngran, eps, stats, gamma, beta);
   });
   KD6D_CHECK_LAUNCH("kd6d_gn_relu_fwd");
   return KD6D_OK;
@@ -758,7 +802,7 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, co
 
 extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx,
                                 const int32_t* level_hw_host, int nseg, int batch, int C, int groups,
-                                const float* gamma, const float* beta, const float* stats,
+                                const float* gamma, const float* beta, float eps, const float* stats,
                                 float* gsum_ws, float* dgamma, float* dbeta, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_gn_relu_bwd");
   if (rc) return rc;
@@ -771,11 +815,16 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
   const size_t lds = (size_t)2 * C * sizeof(float);
+  KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_bwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
+  if (hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
+    kd6d_set_error("kd6d_gn_relu_bwd: memset failed");
+    return KD6D_ERR_LAUNCH;
+  }
   DISPATCH_TTX(dtype, x_f32, {
-    hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<T_, TX_>), dim3(nseg * batch), dim3(kThreads), lds, st,
-                       (const TX_*)x, (const T_*)dz, gm, stats, gamma, beta, gsum_ws, dgamma, dbeta);
+    hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<T_, TX_>), dim3(gm.nblk), dim3(kThreads), lds, st,
+                       (const TX_*)x, (const T_*)dz, gm, eps, stats, gamma, beta, gsum_ws, dgamma, dbeta);
     hipLaunchKernelGGL((gn_relu_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x,
-                       (const T_*)dz, (T_*)dx, gm, ngran, stats, gsum_ws, gamma, beta);
+                       (const T_*)dz, (T_*)dx, gm, ngran, eps, stats, gsum_ws, gamma, beta);
   });
   KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd");
   return KD6D_OK;

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(kT) void clip_adamw_kernel(float* __restrict__ p, c
                                                         long long n, const float* __restrict__ gnorm_sq,
                                                         float max_norm, float lr, float beta1, float beta2,
                                                         float eps, float wd, float bc1, float bc2_sqrt,
+                                                        const float* __restrict__ hyper,
                                                         bf16_t* __restrict__ shadow) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }   // graph-replay path: device-resident schedule
   float coef = 1.f;
   if (gnorm_sq && max_norm > 0.f) {
     const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);
@@ -55,6 +57,10 @@ __global__ __launch_bounds__(kT) void clip_adamw_kernel(float* __restrict__ p, c
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (shadow) shadow[i] = (bf16_t)pi;
   }
+}
+
+__global__ void set_hyper_kernel(float* __restrict__ hyper, float lr, float bc1, float bc2_sqrt) {
+  hyper[0] = lr; hyper[1] = bc1; hyper[2] = bc2_sqrt; hyper[3] = 0.f;
 }
 
 __global__ __launch_bounds__(kT) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
@@ -83,16 +89,28 @@ extern "C" int kd6d_sumsq(const float* x, int64_t n, float* out, void* stream) {
 
 extern "C" int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                const float* gnorm_sq, double max_norm, double lr, double beta1, double beta2,
-                               double eps, double weight_decay, int64_t step, void* bf16_shadow, void* stream) {
-  KD6D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "kd6d_clip_adamw: bad arguments");
+                               double eps, double weight_decay, int64_t step, const float* hyper_dev,
+                               void* bf16_shadow, void* stream) {
+  KD6D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || hyper_dev),
+                 "kd6d_clip_adamw: bad arguments");
   // bias corrections in double, like torch's python-float arithmetic
-  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  const float bc1 = hyper_dev ? 1.f : (float)(1.0 - pow(beta1, (double)step));
+  const float bc2_sqrt = hyper_dev ? 1.f : (float)sqrt(1.0 - pow(beta2, (double)step));
   hipLaunchKernelGGL(clip_adamw_kernel, dim3(blocks_for(n)), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream),
                      param, grad, exp_avg, exp_avg_sq, (long long)n, gnorm_sq, (float)max_norm, (float)lr,
-                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1, bc2_sqrt,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1, bc2_sqrt, hyper_dev,
                      reinterpret_cast<bf16_t*>(bf16_shadow));
   KD6D_CHECK_LAUNCH("kd6d_clip_adamw");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_set_hyper(float* hyper_dev, double lr, double beta1, double beta2, int64_t step, void* stream) {
+  KD6D_CHECK_ARG(hyper_dev && step >= 1, "kd6d_set_hyper: bad arguments");
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), hyper_dev,
+                     (float)lr, bc1, bc2_sqrt);
+  KD6D_CHECK_LAUNCH("kd6d_set_hyper");
   return KD6D_OK;
 }
 

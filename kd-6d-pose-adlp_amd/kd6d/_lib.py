@@ -14,7 +14,7 @@ KD6D_BF16 = 0
 KD6D_F32 = 1
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 MAX_SEG = 5
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Seg(ctypes.Structure):
@@ -60,7 +60,7 @@ SIGNATURES = {
     "kd6d_bn_train_bwd_reduce": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "kd6d_bn_train_bwd_apply": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _P],
-    "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _P,
+    "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P,
                          _P, _P, _P, _P],
     "kd6d_maxpool2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
     "kd6d_maxpool2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -80,7 +80,8 @@ SIGNATURES = {
     "kd6d_loss_backward": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I,
                            _P, _P, _P],
     "kd6d_sumsq": [_P, _I64, _P, _P],
-    "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P],
+    "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
+    "kd6d_set_hyper": [_P, _D, _D, _D, _I64, _P],
     "kd6d_cast_f32_to_bf16": [_P, _P, _I64, _P],
 }
 _RESTYPE = {"kd6d_last_error": ctypes.c_char_p}

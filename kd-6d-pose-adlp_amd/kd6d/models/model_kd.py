@@ -205,5 +205,5 @@ class PoseModuleKD(nn.Module):
         self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.storage(net.scales, "grads"))
         net.backward(dcls, dreg)
         from ..libs import distributed as D
-        if D.get_world_size() > 1:
-            D.allreduce_mean_(st.grads[:st.n_train])
+        if D.get_world_size() > 1 and not getattr(self, "_defer_allreduce", False):
+            D.allreduce_mean_(st.grads[:st.n_train])      # GraphedKDStep issues it between its two graphs

@@ -44,18 +44,18 @@ def profile_begin():
 
 
 def profile_end():
-    """-> list of (kind, algorithmic_flops, milliseconds) for every bracketed launch."""
+    """-> list of (kind, algorithmic_flops, milliseconds, tag) for every bracketed launch."""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
-    return [(k, f, e0.elapsed_time(e1)) for (k, f, e0, e1) in rec]
+    return [(k, f, e0.elapsed_time(e1), t) for (k, f, e0, e1, t) in rec]
 
 
 class _Timed:
-    __slots__ = ("kind", "flops", "e0")
+    __slots__ = ("kind", "flops", "e0", "tag")
 
-    def __init__(self, kind, flops):
-        self.kind, self.flops, self.e0 = kind, flops, None
+    def __init__(self, kind, flops, tag=None):
+        self.kind, self.flops, self.e0, self.tag = kind, flops, None, tag
 
     def __enter__(self):
         if _prof is not None:
@@ -66,7 +66,7 @@ class _Timed:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _prof.append((self.kind, self.flops, self.e0, e1))
+            _prof.append((self.kind, self.flops, self.e0, e1, self.tag))
 
 
 class Geom:
@@ -109,7 +109,7 @@ def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE,
     for v in (ch_scale, ch_shift):
         assert v is None or (v.dtype == torch.float32 and v.numel() >= geom.cout)
     assert seg_scale is None or (seg_scale.dtype == torch.float32 and seg_scale.numel() >= len(geom.levels_in))
-    with _Timed("conv_fwd", flops):
+    with _Timed("conv_fwd", flops, geom):
         check(lib.kd6d_conv2d_fwd(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(out), _ptr(ch_scale),
                                   _ptr(ch_shift), act, _ptr(residual), _ptr(seg_scale), int(out_f32),
                                   _stream()), "kd6d_conv2d_fwd")
@@ -123,7 +123,7 @@ def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
         assert not accumulate
         dx = torch.empty((geom.rows_in, geom.cin), dtype=dy.dtype, device=dy.device)
     assert dx.shape == (geom.rows_in, geom.cin) and dx.dtype == dy.dtype
-    with _Timed("conv_dgrad", flops):
+    with _Timed("conv_dgrad", flops, geom):
         check(lib.kd6d_conv2d_dgrad(geom.ref, dt_code(dy.dtype), _ptr(dy), _ptr(wt), _ptr(dx),
                                     int(accumulate), _stream()), "kd6d_conv2d_dgrad")
     return dx
@@ -133,7 +133,7 @@ def conv2d_wgrad(geom, x, dy, dw, flops=0):
     assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
     assert x.dtype == dy.dtype and dw.dtype == torch.float32
     assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
-    with _Timed("conv_wgrad", flops):
+    with _Timed("conv_wgrad", flops, geom):
         check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _stream()),
               "kd6d_conv2d_wgrad")
     return dw
@@ -194,11 +194,11 @@ def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats):
     return y
 
 
-def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta):
+def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta, eps=1e-5):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
     check(lib.kd6d_gn_relu_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
-                               len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), _ptr(stats),
+                               len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats),
                                _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), _stream()), "kd6d_gn_relu_bwd")
     return dx
 

@@ -21,13 +21,28 @@ class FusedClipAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)     # lr, 1-b1^t, sqrt(1-b2^t): graph-replay form
         self.steps = 0
 
     @torch.no_grad()
     def step(self, closure=None):
-        st = self.net.store
+        self.advance()
+        self.launch(device_schedule=False)
+
+    def advance(self):
+        """Host half of a step: count it and publish (lr, bias corrections) to the device.  In graph
+        mode this runs eagerly before every replay of the captured `launch(device_schedule=True)`."""
         g = self.param_groups[0]
         self.steps += 1
+        check(lib.kd6d_set_hyper(ops._ptr(self.hyper), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                 self.steps, ops._stream()), "kd6d_set_hyper")
+
+    @torch.no_grad()
+    def launch(self, device_schedule=True):
+        """Device half: sum of squares + fused clip/AdamW (+ bf16 shadow refresh).  With
+        device_schedule the launch carries no per-step host scalar and can be captured in a hipGraph."""
+        st = self.net.store
+        g = self.param_groups[0]
         n = st.n_train
         P = ops._ptr
         s = ops._stream()
@@ -36,7 +51,8 @@ class FusedClipAdamW(torch.optim.Optimizer):
         shadow = st.ensure_shadow() if self.net.dtype == torch.bfloat16 else None
         check(lib.kd6d_clip_adamw(P(st.params), P(st.grads), P(self.exp_avg), P(self.exp_avg_sq), n, P(self.gnorm_sq),
                                   float(self.max_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                  float(g["eps"]), float(g["weight_decay"]), self.steps, P(shadow), s), "kd6d_clip_adamw")
+                                  float(g["eps"]), float(g["weight_decay"]), max(self.steps, 1),
+                                  P(self.hyper) if device_schedule else None, P(shadow), s), "kd6d_clip_adamw")
         self.net._weights_dirty = shadow is None and self.net.dtype == torch.bfloat16
         for _, bn in self.net.bns:
             bn.fold = None

@@ -382,8 +382,14 @@ def test_fused_clip_adamw_matches_torch(gpu_device):
         gd = grad.to(dev)
         ss = torch.zeros(1, device=dev)
         ops.check(lib.kd6d_sumsq(P(gd), n, P(ss), ops._stream()))
-        ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(ss), 1.0, lr, 0.9, 0.999, 1e-8, 1e-4, step,
-                                      P(shadow), ops._stream()))
+        if step % 2:       # host-scalar form
+            ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(ss), 1.0, lr, 0.9, 0.999, 1e-8, 1e-4, step,
+                                          None, P(shadow), ops._stream()))
+        else:              # device-resident schedule (the hipGraph replay form); host lr/step args are ignored
+            hyper = torch.zeros(4, device=dev)
+            ops.check(lib.kd6d_set_hyper(P(hyper), lr, 0.9, 0.999, step, ops._stream()))
+            ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(ss), 1.0, 123.0, 0.9, 0.999, 1e-8, 1e-4, 0,
+                                          P(hyper), P(shadow), ops._stream()))
         torch.cuda.synchronize()
         assert float(ss) == pytest.approx(float((grad.double() ** 2).sum()), rel=1e-5)
         torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-5, atol=1e-6)
@@ -394,6 +400,6 @@ def test_fused_clip_adamw_matches_torch(gpu_device):
     for it in range(3):
         gd = torch.randn(16, generator=g).to(dev)
         ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), 16, None, 0.0, float(z["lrs"][it]), 0.9, 0.999, 1e-8,
-                                      1e-4, it + 1, None, ops._stream()))
+                                      1e-4, it + 1, None, None, ops._stream()))
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), z["params"][it], rtol=1e-5, atol=1e-7)
