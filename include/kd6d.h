@@ -71,11 +71,15 @@ int kd6d_abi_version(void);
  * Implicit GEMM on MFMA, weights KRSC: w[cout][ky][kx][cin].
  *   y = act((conv(x) * ch_scale[c] + ch_shift[c]) * seg_scale[level]) + residual
  * ch_scale/ch_shift/seg_scale/residual may be NULL.  out_f32 != 0 writes fp32
- * regardless of dtype. */
+ * regardless of dtype.
+ * stats (optional, caller-zeroed): statistics of the stored y accumulated by the epilogue with fp32
+ * atomics, so that the normalisation that follows needs no separate reduction pass:
+ *   stats_groups == 0: {sum[cout], sumsq[cout]}           (BatchNorm batch statistics, = kd6d_colstats)
+ *   stats_groups  > 0: {sum, sumsq} per (level, image, group), the layout kd6d_gn_relu_fwd consumes. */
 int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x,
                     const void* w, void* y, const float* ch_scale,
                     const float* ch_shift, int act, const void* residual,
-                    const float* seg_scale, int out_f32, void* stream);
+                    const float* seg_scale, int out_f32, float* stats, int stats_groups, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  wt is the dgrad packing wt[cin][ky][kx][cout]
  * produced by kd6d_pack_dgrad_weights.  accumulate != 0 adds into dx. */
@@ -83,9 +87,10 @@ int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void* dy,
                       const void* wt, void* dx, int accumulate, void* stream);
 
 /* dw[cout][ky][kx][cin] += sum_pixels dy (x) x   (fp32 atomics, dw pre-zeroed
- * or holding a running sum). */
+ * or holding a running sum).  dbias (optional): dbias[cout] += sum_pixels dy, the bias gradient of
+ * the same layer, taken from the dY tiles the kernel stages anyway. */
 int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x,
-                      const void* dy, float* dw, void* stream);
+                      const void* dy, float* dw, float* dbias, void* stream);
 
 /* wt[cin][ky][kx][cout] <- w[cout][ky][kx][cin] for n_layers layers in one
  * launch.  desc_dev: int32[n_layers*6] = {w_off, wt_off, cout, cin, ksize,
@@ -132,14 +137,19 @@ int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz,
 /* GroupNorm(groups)+ReLU of the PoseHead towers (models/model.py:395-417) over a multi-level
  * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 floats per
  * (level, image, group) = RAW sums {sum x, sum x^2} (mean/rstd are derived by the consumers, which is
- * why the backward takes eps too); gsum_ws: workspace of the same size.  Both are zeroed by the call
- * (a memset node on `stream`).  Requires C/groups >= granule/2 (a 16-B granule spans <= 2 groups). */
+ * why the backward takes eps too); gsum_ws: workspace of the same size.
+ * flags: bit 0 (KD6D_GN_STATS_READY) -- stats were already accumulated by kd6d_conv2d_fwd(..., stats,
+ * groups): skip the reduction pass; bit 1 (KD6D_GN_WS_ZEROED) -- the caller zeroed stats (fwd, when not
+ * ready) / gsum_ws (bwd) itself (e.g. one memset of a whole scratch arena per step): skip the memset node.
+ * Requires C/groups >= granule/2 (a 16-B granule spans <= 2 groups). */
+#define KD6D_GN_STATS_READY 1
+#define KD6D_GN_WS_ZEROED 2
 int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host, int nseg, int batch,
                      int C, int groups, const float* gamma, const float* beta, float eps, float* stats,
-                     void* stream);
+                     int flags, void* stream);
 int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, const int32_t* level_hw_host,
                      int nseg, int batch, int C, int groups, const float* gamma, const float* beta, float eps,
-                     const float* stats, float* gsum_ws, float* dgamma, float* dbeta, void* stream);
+                     const float* stats, float* gsum_ws, float* dgamma, float* dbeta, int flags, void* stream);
 
 /* MaxPool2d(2,2) (backbone/darknet.py:94-97), nearest-x2 upsample + add (models/model.py:75-78)
  * and its adjoint, ReLU / ReLU-backward / add (mode 0/1/2), NCHW fp32 image -> padded NHWC. */

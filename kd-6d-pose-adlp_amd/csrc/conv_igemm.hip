@@ -55,6 +55,10 @@ struct ConvParams {
   const float* seg_scale;
   int act;
   int out_f32;
+  float* stats;        // optional fused statistics of the stored values (see conv_epilogue_stats)
+  int stats_groups;    // 0: per channel {sum[N], sumsq[N]} (BatchNorm); G > 0: {sum, sumsq} per (level, image, group)
+  int stats_cpg_shift; // log2(channels per group): 2 or 3
+  float seg_inv_hw[kMaxSeg];   // 1 / (dst_h * dst_w) per level (division-free image index)
 };
 
 template <typename T> struct Frag;
@@ -137,6 +141,234 @@ __device__ __forceinline__ RowInfo decode_row(const ConvParams& p, int m) {
   r.seg = sg;
   if (m >= p.M) { r.src_h = 0; r.src_w = 0; }
   return r;
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane.  VALU-only (v_add_f32
+// with dpp modifiers): the ds_bpermute form of __shfl_xor costs an LDS round trip per step.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// Fused normalisation statistics of a conv output (replaces a separate pass over the fp32 tensor).
+// acc holds the FINAL values (what was stored).  Per-channel mode (BatchNorm batch statistics):
+// registers -> 16-lane shuffle -> LDS (one slot per channel of the tile) -> one global atomic per
+// channel and workgroup.  Group mode (GroupNorm): a 16-pixel fragment normally lies inside one
+// (level, image); its 4-channel lane sums are shuffled down to one atomic pair per group, else
+// (tiny levels, several images per fragment) every lane adds its own 4-channel partial.
+template <int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
+                                                    int m0, int n0, int wp, int wc, int lane, float* red) {
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  if (p.stats_groups == 0) {
+    __syncthreads();                       // staging buffers are dead from here on
+    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < PI; ++q) {
+        const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+        const bool ok = m < p.M && n0 + nl < p.N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = ok ? acc[c][q][r] : 0.f;
+          s1[r] += v;
+          s2[r] += v * v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] = row16_sum(s1[r]);
+        s2[r] = row16_sum(s2[r]);
+      }
+      if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(&red[nl + r], s1[r]);
+          atomicAdd(&red[BC + nl + r], s2[r]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
+      const int which = i / BC, nl = i - which * BC;
+      if (n0 + nl < p.N) atomicAdd(p.stats + (size_t)which * p.N + n0 + nl, red[i]);
+    }
+    return;
+  }
+  // ---- group mode: LDS table [image of the tile][group of the tile] -> one full-width flush ----
+  const int G = p.stats_groups;
+  const int cs = p.stats_cpg_shift;        // 4 or 8 channels per group: a lane's 4 aligned channels share one
+  const int GT = BC >> cs;                 // groups touched by this channel tile
+  auto key_of = [&](int m) {
+    int mb = 0, hw = 1, sg = 0;
+    float inv = 1.f;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s)
+      if (s < p.nseg && m >= p.seg[s].m_begin) {
+        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg_inv_hw[s];
+      }
+    // (m - mb) / hw without an integer division (operands < 2^24): float estimate, then one correction step
+    const int xx = m - mb;
+    int b = (int)((float)xx * inv);
+    b += ((b + 1) * hw <= xx) ? 1 : 0;
+    b -= (b * hw > xx) ? 1 : 0;
+    return sg * p.batch + b;               // monotone in m: levels are packed level-major, image-major
+  };
+  const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
+  const int key_lo = key_of(m0);
+  const int nkeys = key_of(m_last) - key_lo + 1;
+  const int tab = nkeys * GT * 2;          // <= BP * BC / 2 floats: fits the dead staging buffers
+  __syncthreads();
+  for (int i = threadIdx.x; i < tab; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  // a 16-pixel fragment normally lies inside one image: DPP row sum, one writer lane per 4-channel slice;
+  // otherwise (tiny levels, several images per fragment) every lane adds its own partial
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+    const bool mok = m < p.M;
+    const int key = mok ? key_of(m) - key_lo : 0;
+    const int key0 = __shfl(key, lane & 48, 64);
+    const bool uniform = __all(!mok || key == key0);     // rows past M sit at the tail of the last fragment
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+      const bool ok = mok && n0 + nl < p.N;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ok ? acc[c][q][r] : 0.f;
+        s1 += v;
+        s2 += v * v;
+      }
+      if (uniform) {
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (fr == 0 && n0 + nl < p.N) {
+          float* o2 = red + ((key0 * GT + (nl >> cs)) << 1);
+          atomicAdd(o2, s1);
+          atomicAdd(o2 + 1, s2);
+        }
+      } else if (ok) {
+        float* o2 = red + ((key * GT + (nl >> cs)) << 1);
+        atomicAdd(o2, s1);
+        atomicAdd(o2 + 1, s2);
+      }
+    }
+  }
+  __syncthreads();
+  const int g_first = n0 >> cs;
+  const int gts = 31 - __clz(GT * 2);      // GT * 2 is a power of two
+  for (int i = threadIdx.x; i < tab; i += blockDim.x) {
+    const int k = i >> gts, rem = i & (GT * 2 - 1);
+    const int gl = rem >> 1;
+    if (g_first + gl < G) atomicAdd(p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1), red[i]);
+  }
+}
+
+// Epilogue shared by the register-staged and the LDS-DMA kernels: lane owns pixel (lane&15),
+// channels (lane>>4)*4 .. +3 of every 16x16 accumulator tile.
+template <typename T, int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
+                                              int m0, int n0, int wp, int wc, int lane, float* smem_f32) {
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+    if (m >= p.M) continue;
+    int drow = m, sg = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) {
+      if (s < p.nseg && m >= p.seg[s].m_begin) {
+        drow = p.seg[s].dst_row0 + (m - p.seg[s].m_begin);
+        sg = s;
+      }
+    }
+    float sscale = 1.f;
+    if (p.seg_scale) sscale = p.seg_scale[sg];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]};
+      const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
+      if (vec_ok) {
+        if (p.ch_scale) {
+          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= s4[r];
+        }
+        if (p.ch_shift) {
+          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += s4[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= sscale;
+          if (p.act == KD6D_ACT_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+          else if (p.act == KD6D_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.residual) {
+          if (p.out_f32) {
+            const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(
+                reinterpret_cast<const float*>(p.residual) + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += r4[r];
+          } else {
+            const T* rp = reinterpret_cast<const T*>(p.residual) + o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+          }
+        }
+        if (p.stats) acc[c][q] = f32x4_t{v[0], v[1], v[2], v[3]};
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
+              f32x4_t{v[0], v[1], v[2], v[3]};
+        } else if (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
+              f32x4_t{v[0], v[1], v[2], v[3]};
+        } else {
+          u32x2_t pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.N) continue;
+          float t = v[r];
+          if (p.ch_scale) t *= p.ch_scale[n + r];
+          if (p.ch_shift) t += p.ch_shift[n + r];
+          t *= sscale;
+          if (p.act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+          else if (p.act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+          if (p.residual) {
+            t += p.out_f32 ? reinterpret_cast<const float*>(p.residual)[o + r]
+                           : to_f32<T>(reinterpret_cast<const T*>(p.residual)[o + r]);
+          }
+          if (p.out_f32) reinterpret_cast<float*>(p.dst)[o + r] = t;
+          else reinterpret_cast<T*>(p.dst)[o + r] = from_f32<T>(t);
+        }
+      }
+    }
+  }
+  if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
 }
 
 template <typename T, int BP, int BC, int WP, int WC, int MODE>
@@ -289,89 +521,357 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 -------
-  const bool vec_ok = (p.N & 3) == 0;
+  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+}
+
+// ---------------------------------------------------------------------------
+// bf16 implicit GEMM with LDS-DMA staging (the kernel the step uses for N > 32).
+//
+// Same tile image and fragment reads as above, but the tiles travel global -> LDS directly
+// (global_load_lds_dwordx4, no staging registers, no ds_write) into a ring of NSTAGE buffers so
+// that NSTAGE-1 k-steps are in flight while one is multiplied: these layers are short-K / small-M
+// and were bound by the global-load round trip of a 2-deep register pipeline, not by MFMA.
+// One wave-instruction fills 8 rows x 128 B; lane l lands at slot l&7 of row l>>3, so it FETCHES
+// the k-granule (l&7)^(l>>3) -- the XOR swizzle is applied to the source address (the LDS side of
+// an LDS-DMA is linear).  Zero padding / tails fetch from a zero page.  One raw s_barrier per
+// k-step; loads are retired with counted s_waitcnt vmcnt so they stay in flight across barriers.
+// ---------------------------------------------------------------------------
+__device__ const uint4 kd6d_zero_page[4] = {};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p) {
+  using T = bf16_t;
+  constexpr int BK = 64;
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  constexpr int PR = BP / 32;   // pixel rows fetched per lane per k-step (8 rows per wave-instruction)
+  constexpr int CR = BC / 32;
+  constexpr int L = PR + CR;    // LDS-DMA instructions per wave per k-step
+  constexpr int STAGE = (BP + BC) * 128;
+  static_assert(WP * WC == 4 && BP % 32 == 0 && BC % 32 == 0 && PI >= 1 && CI >= 1, "tile shape");
+  static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+  static_assert((NSTAGE - 2) * L <= 63, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wp = wave % WP;
+  const int wc = wave / WP;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_c = wg % p.n_ctiles;
+  const int tile_p = wg / p.n_ctiles;
+  const int m0 = tile_p * BP;
+  const int n0 = tile_c * BC;
+
+  // ---- loader state: lane -> row (lane>>3) of each 8-row group, k-granule (lane&7)^(lane>>3) ----
+  const int lrow = lane >> 3;
+  const int gk = (lane & 7) ^ lrow;
+  int ry[PR], rx[PR], rbase[PR], rhw[PR];
+#pragma unroll
+  for (int i = 0; i < PR; ++i) {
+    const int prow = 8 * (wave + 4 * i) + lrow;
+    RowInfo ri = decode_row(p, m0 + prow);
+    if (MODE == MODE_FWD) {
+      ry[i] = ri.y * p.stride - p.pad;
+      rx[i] = ri.x * p.stride - p.pad;
+    } else {
+      ry[i] = ri.y + p.pad;
+      rx[i] = ri.x + p.pad;
+    }
+    rbase[i] = ri.src_base;
+    rhw[i] = (ri.src_h << 16) | ri.src_w;
+  }
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+  const char* zero = reinterpret_cast<const char*>(kd6d_zero_page);
+  int wofs[CR];   // element offset of the lane's weight row, or -1
+#pragma unroll
+  for (int i = 0; i < CR; ++i) {
+    const int n = n0 + 8 * (wave + 4 * i) + lrow;
+    wofs[i] = n < p.N ? n * p.K : -1;
+  }
+
+  // k-granule decode, advanced incrementally (one wrap per k-step at most when C >= 64)
+  int kk = gk * 8;
+  int cc, ky, kx;
+  {
+    const int tap = kk / p.C;
+    cc = kk - tap * p.C;
+    ky = tap / p.ks;
+    kx = tap - ky * p.ks;
+  }
+
+  auto issue = [&](int stage) {
+    char* base = smem + stage * STAGE + wave * 1024;
+    const bool kvalid = kk < p.K;
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const int sh = rhw[i] >> 16, sw = rhw[i] & 0xffff;
+      int sy, sx;
+      bool ok = kvalid;
+      if (MODE == MODE_FWD) {
+        sy = ry[i] + ky;
+        sx = rx[i] + kx;
+      } else {
+        const int ty = ry[i] - ky, tx = rx[i] - kx;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (p.stride == 1) {
+          sy = ty; sx = tx;
+        } else {
+          sy = ty / p.stride; sx = tx / p.stride;
+          ok = ok && (sy * p.stride == ty) && (sx * p.stride == tx);
+        }
+      }
+      ok = ok && (unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw;
+      const void* g = zero;
+      if (ok) g = src + ((size_t)(rbase[i] + sy * sw + sx) * (size_t)p.C + (size_t)cc);
+      glds16(g, base + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < CR; ++i) {
+      const void* g = zero;
+      if (kvalid && wofs[i] >= 0) g = wgt + ((size_t)wofs[i] + (size_t)kk);
+      glds16(g, base + BP * 128 + i * 4096);
+    }
+    // advance to the next k-step
+    kk += BK;
+    if (p.C >= BK) {
+      cc += BK;
+      if (cc >= p.C) {
+        cc -= p.C;
+        if (++kx == p.ks) { kx = 0; ++ky; }
+      }
+    } else {
+      const int tap = kk / p.C;
+      cc = kk - tap * p.C;
+      ky = tap / p.ks;
+      kx = tap - ky * p.ks;
+    }
+  };
+
+  f32x4_t acc[CI][PI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c)
+#pragma unroll
+    for (int q = 0; q < PI; ++q) acc[c][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s);
+
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire this k-step's loads, keep the younger stages in flight
+    if (NSTAGE == 4 && kt + 2 < nk) wait_vmcnt<(NSTAGE - 2) * L>();
+    else if (kt + 1 < nk) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) {
+      int st2 = stage + NSTAGE - 1;
+      if (st2 >= NSTAGE) st2 -= NSTAGE;
+      issue(st2);
+    }
+    const char* ptile = smem + stage * STAGE;
+    const char* ctile = ptile + BP * 128;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      Frag<T> fa[CI], fb[PI];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) load_frag<T>(ctile, wc * (BC / WC) + c * 16 + fr, ch, fq, fa[c]);
+#pragma unroll
+      for (int q = 0; q < PI; ++q) load_frag<T>(ptile, wp * (BP / WP) + q * 16 + fr, ch, fq, fb[q]);
+#pragma unroll
+      for (int c = 0; c < CI; ++c)
+#pragma unroll
+        for (int q = 0; q < PI; ++q) mma(fa[c], fb[q], acc[c][q]);
+    }
+    if (++stage == NSTAGE) stage = 0;
+  }
+  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, bf16, C % 64 == 0: "halo patch" implicit GEMM.
+//
+// The generic kernels fetch the im2col operand tap by tap, i.e. every input pixel 9 times, and
+// at these layer sizes they are bound by the ~28 B/clk a CU can pull from its XCD's L2, not by
+// MFMA.  Here a workgroup keeps the input pixels of its tile PLUS a halo (packed rows
+// [m0 - halo, m0 + BP + halo), halo = max level width + 1) resident in LDS for one 64-channel
+// chunk and builds all 9 taps from it: the pixel operand is fetched once instead of 9 times, so a
+// k-step streams only the weight tile (BC x 128 B).  The MFMA pixel fragment of tap (dy,dx) is a
+// plain ds_read_b128 at patch row (m - patch_lo) + dy*W + dx; out-of-image taps read a zero row.
+// k order is (chunk, tap, ci) instead of (tap, ci): only the fp32 summation order changes.
+// Everything travels by LDS-DMA: weights through a 3-deep ring (BC/8/waves instructions per wave
+// and k-step), the next chunk's patch double-buffered behind the current one; counted vmcnt,
+// one raw s_barrier per k-step.  Levels of a multi-level (head) launch may share a tile.
+// ---------------------------------------------------------------------------
+template <int BP, int BC, int WP, int WC, int MODE>
+__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
+  using T = bf16_t;
+  constexpr int NW = WP * WC;
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;   // 8-row groups of a patch (+1: the zero row lives in the last)
+  constexpr int PL = (PSLOT + NW - 1) / NW;          // patch LDS-DMA instructions per wave per chunk
+  constexpr int PATCH_BYTES = PL * NW * 1024;
+  constexpr int ZERO_ROW = PL * NW * 8 - 1;          // never a real patch row: always filled from the zero page
+  constexpr int WL = BC / 8 / NW;                    // weight LDS-DMA instructions per wave per k-step
+  constexpr int WSTAGE = BC * 128;
+  static_assert(BC % (8 * NW) == 0 && PI >= 1 && CI >= 1, "tile shape");
+  static_assert(WL + PL <= 63, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const pbuf = smem;                       // 2 patch buffers
+  char* const wring = smem + 2 * PATCH_BYTES;    // 3 weight stages
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wp = wave % WP;
+  const int wc = wave / WP;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_c = wg % p.n_ctiles;
+  const int tile_p = wg / p.n_ctiles;
+  const int m0 = tile_p * BP;
+  const int n0 = tile_c * BC;
+  const int patch_lo = m0 - halo;
+
+  const int lrow = lane >> 3;
+  const int gk = (lane & 7) ^ lrow;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+  const char* zero = reinterpret_cast<const char*>(kd6d_zero_page);
+
+  // ---- per-lane pixel fragments: patch row of the centre tap, level width, 9-bit tap validity ----
+  int pbase[PI], pw[PI], pmask[PI];
 #pragma unroll
   for (int q = 0; q < PI; ++q) {
     const int m = m0 + wp * (BP / WP) + q * 16 + fr;
-    if (m >= p.M) continue;
-    int drow = m, sg = 0;
+    const RowInfo ri = decode_row(p, m);      // packed identically on both sides: src row == dst row == m
+    pbase[q] = m - patch_lo;
+    pw[q] = ri.src_w;
+    int mask = 0;
 #pragma unroll
-    for (int s = 0; s < kMaxSeg; ++s) {
-      if (s < p.nseg && m >= p.seg[s].m_begin) {
-        drow = p.seg[s].dst_row0 + (m - p.seg[s].m_begin);
-        sg = s;
-      }
+    for (int t = 0; t < 9; ++t) {
+      const int dy = MODE == MODE_FWD ? t / 3 - 1 : 1 - t / 3;
+      const int dx = MODE == MODE_FWD ? t % 3 - 1 : 1 - t % 3;
+      const bool ok = (unsigned)(ri.y + dy) < (unsigned)ri.src_h && (unsigned)(ri.x + dx) < (unsigned)ri.src_w;
+      mask |= ok ? (1 << t) : 0;
     }
-    float sscale = 1.f;
-    if (p.seg_scale) sscale = p.seg_scale[sg];
+    pmask[q] = m < p.M ? mask : 0;
+  }
+
+  // ---- loaders ----
+  int wofs[WL];
 #pragma unroll
-    for (int c = 0; c < CI; ++c) {
-      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]};
-      const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
-      if (vec_ok) {
-        if (p.ch_scale) {
-          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+  for (int i = 0; i < WL; ++i) {
+    const int n = n0 + 8 * (wave + NW * i) + lrow;
+    wofs[i] = n < p.N ? n * p.K + gk * 8 : -1;
+  }
+  auto issue_w = [&](int stage, int chunk, int tap) {
+    char* base = wring + stage * WSTAGE + wave * 1024;
+    const int kk0 = tap * p.C + chunk * 64;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= s4[r];
-        }
-        if (p.ch_shift) {
-          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+    for (int i = 0; i < WL; ++i) {
+      const void* g = zero;
+      if (wofs[i] >= 0) g = wgt + ((size_t)wofs[i] + (size_t)kk0);
+      glds16(g, base + i * NW * 1024);
+    }
+  };
+  auto issue_patch = [&](int buf, int chunk) {
+    char* base = pbuf + buf * PATCH_BYTES + wave * 1024;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += s4[r];
-        }
+    for (int i = 0; i < PL; ++i) {
+      const int slot = wave + NW * i;
+      const int prow = 8 * slot + lrow;
+      const int row = patch_lo + prow;
+      const void* g = zero;
+      if (prow < BP + 2 * halo && row >= 0 && row < total_rows)
+        g = src + ((size_t)row * (size_t)p.C + (size_t)(chunk * 64 + gk * 8));
+      glds16(g, base + i * NW * 1024);
+    }
+  };
+
+  f32x4_t acc[CI][PI];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] *= sscale;
-          if (p.act == KD6D_ACT_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
-          else if (p.act == KD6D_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.residual) {
-          if (p.out_f32) {
-            const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(
-                reinterpret_cast<const float*>(p.residual) + o);
+  for (int c = 0; c < CI; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += r4[r];
-          } else {
-            const T* rp = reinterpret_cast<const T*>(p.residual) + o;
+    for (int q = 0; q < PI; ++q) acc[c][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = p.C >> 6;
+  const int nk = nchunk * 9;
+
+  // prologue: queue = [PATCH(0), W(0), W(1)]
+  issue_patch(0, 0);
+  issue_w(0, 0, 0);
+  issue_w(1, 0, 1);
+  int wstage = 0;              // ring slot of W(kt)
+  int c2 = 0, t2 = 2;          // (chunk, tap) of W(kt+2)
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const bool more_patch = chunk + 1 < nchunk;
+    const char* patch = pbuf + (chunk & 1) * PATCH_BYTES;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
-          }
-        }
-        if (p.out_f32) {
-          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
-              f32x4_t{v[0], v[1], v[2], v[3]};
-        } else if (sizeof(T) == 4) {
-          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
-              f32x4_t{v[0], v[1], v[2], v[3]};
-        } else {
-          u32x2_t pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= p.N) continue;
-          float t = v[r];
-          if (p.ch_scale) t *= p.ch_scale[n + r];
-          if (p.ch_shift) t += p.ch_shift[n + r];
-          t *= sscale;
-          if (p.act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
-          else if (p.act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
-          if (p.residual) {
-            t += p.out_f32 ? reinterpret_cast<const float*>(p.residual)[o + r]
-                           : to_f32<T>(reinterpret_cast<const T*>(p.residual)[o + r]);
-          }
-          if (p.out_f32) reinterpret_cast<float*>(p.dst)[o + r] = t;
-          else reinterpret_cast<T*>(p.dst)[o + r] = from_f32<T>(t);
-        }
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = chunk * 9 + tap;
+      // retire W(kt); W(kt+1) and (taps 1,2) the next chunk's patch stay in flight
+      if (kt + 1 >= nk) wait_vmcnt<0>();
+      else if ((tap == 1 || tap == 2) && more_patch) wait_vmcnt<WL + PL>();
+      else wait_vmcnt<WL>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) {
+        int st2 = wstage + 2;
+        if (st2 >= 3) st2 -= 3;
+        issue_w(st2, c2, t2);
+        if (++t2 == 9) { t2 = 0; ++c2; }
       }
+      if (tap == 0 && more_patch) issue_patch((chunk + 1) & 1, chunk + 1);
+
+      const char* wt = wring + wstage * WSTAGE;
+      const int dy = MODE == MODE_FWD ? tap / 3 - 1 : 1 - tap / 3;
+      const int dx = MODE == MODE_FWD ? tap % 3 - 1 : 1 - tap % 3;
+      int nrow[PI];
+#pragma unroll
+      for (int q = 0; q < PI; ++q) {
+        const int r = pbase[q] + dy * pw[q] + dx;
+        nrow[q] = ((pmask[q] >> tap) & 1) ? r : ZERO_ROW;
+      }
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        Frag<T> fa[CI], fb[PI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) load_frag<T>(wt, wc * (BC / WC) + c * 16 + fr, ch, fq, fa[c]);
+#pragma unroll
+        for (int q = 0; q < PI; ++q) load_frag<T>(patch, nrow[q], ch, fq, fb[q]);
+#pragma unroll
+        for (int c = 0; c < CI; ++c)
+#pragma unroll
+          for (int q = 0; q < PI; ++q) mma(fa[c], fb[q], acc[c][q]);
+      }
+      if (++wstage == 3) wstage = 0;
     }
   }
+  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
 }
 
 // ---------------------------------------------------------------------------
@@ -392,6 +892,7 @@ struct WgradParams {
   const void* x;
   const void* dy;
   float* dw;
+  float* dbias;   // optional: += column sums of dY (bias gradient), accumulated by the j-tile-0 workgroups
 };
 
 template <typename T>
@@ -669,6 +1170,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
   for (int i = 0; i < LN; ++i) nok[i] = (sub + 4 * i < GN) && (n0 + (sub + 4 * i) * 8 < p.Cout);
 
   u32x4_t nreg[LN], jreg[LJ];
+  const bool do_bias = p.dbias != nullptr && tile_j == 0;
+  float bacc[LN][8];
+#pragma unroll
+  for (int i = 0; i < LN; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bacc[i][e] = 0.f;
 
   auto issue_loads = [&](int mstep) {
     const int m = mstep + prow;
@@ -714,6 +1221,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
       if (sub + 4 * i < GN) *reinterpret_cast<u32x4_t*>(ntile + tr_off(prow, sub + 4 * i)) = nreg[i];
 #pragma unroll
     for (int i = 0; i < LJ; ++i) *reinterpret_cast<u32x4_t*>(jtile + tr_off(prow, sub + 4 * i)) = jreg[i];
+    if (do_bias) {          // every dY granule passes through here exactly once per n-tile
+#pragma unroll
+      for (int i = 0; i < LN; ++i) {
+        float v[8];
+        granule_to_f32<bf16_t>(nreg[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bacc[i][e] += v[e];
+      }
+    }
   };
 
   f32x4_t acc[NI][JI];
@@ -750,6 +1266,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
     __syncthreads();
   }
 
+  if (p.dbias != nullptr && tile_j == 0) {
+    // block-level reduction in LDS (the staging buffers are dead: the k-loop ended on a barrier), then
+    // ONE atomic wave-instruction per 64 channels: the memory side retires ~one atomic instruction
+    // per 50 ns per CU however few lanes it carries
+    float* bred = reinterpret_cast<float*>(smem);
+    for (int i = tid; i < BN; i += 256) bred[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LN; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bacc[i][e];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);   // lanes with equal lane&3: same channels
+        if (lane < 4 && sub + 4 * i < GN) atomicAdd(&bred[(sub + 4 * i) * 8 + e], v);
+      }
+    __syncthreads();
+    for (int i = tid; i < BN; i += 256)
+      if (n0 + i < p.Cout) atomicAdd(p.dbias + n0 + i, bred[i]);
+    __syncthreads();
+  }
   // ---- epilogue: [n][j] fp32 image in LDS, then 256-B contiguous atomic rows ----
   float* et = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -860,6 +1397,94 @@ void launch_igemm(const ConvParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q);
 }
 
+template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE>
+void launch_glds(const ConvParams& p, hipStream_t st) {
+  ConvParams q = p;
+  q.n_ctiles = (p.N + BC - 1) / BC;
+  const int ptiles = (p.M + BP - 1) / BP;
+  const size_t lds = (size_t)(BP + BC) * 128 * NSTAGE;
+  auto kern = conv_igemm_glds_kernel<BP, BC, WP, WC, MODE, NSTAGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q);
+}
+
+template <int BP, int BC, int WP, int WC, int MODE>
+void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
+  constexpr int NW = WP * WC;
+  constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;
+  constexpr int PL = (PSLOT + NW - 1) / NW;
+  ConvParams q = p;
+  q.n_ctiles = (p.N + BC - 1) / BC;
+  const int ptiles = (p.M + BP - 1) / BP;
+  const size_t lds = (size_t)2 * PL * NW * 1024 + (size_t)3 * BC * 128;
+  auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(NW * 64), lds, st, q, halo, total_rows);
+}
+
+// 3x3/s1/p1 layers with C % 64 == 0 on maps at most 64 wide, both sides packed identically.
+template <int MODE>
+bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
+  static const int force = []() {
+    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128 (8 waves), 2 = 128x128 (4 waves)
+    return e ? atoi(e) : -1;
+  }();
+  if (force == 0) return false;
+  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C & 63) || p.N < 64) return false;
+  int wmax = 0, rows = 0;
+  for (int s = 0; s < g->nseg; ++s) {
+    const kd6d_seg& q = g->seg[s];
+    if (q.in_row0 != q.out_row0 || q.in_row0 != rows) return false;
+    if (q.in_w > wmax) wmax = q.in_w;
+    rows += g->batch * q.in_h * q.in_w;
+  }
+  if (wmax > 64) return false;
+  const int halo = wmax + 1;
+  // measured on the step's layers (tools/bench_conv.py): the 8-wave 256x128 tile wins once it yields
+  // >= 150 workgroups, the 4-wave 128x128 tile from >= 250; below that the tail of the last round
+  // outweighs the saved L2 traffic and the generic kernel's smaller tiles are faster
+  const int ct = (p.N + 127) / 128;
+  int pick = 0;
+  if (((p.M + 255) / 256) * ct >= 150) pick = 1;
+  else if (((p.M + 127) / 128) * ct >= 250) pick = 2;
+  if (force > 0) pick = force;
+  if (pick == 0) return false;
+  if (pick == 1) launch_halo<256, 128, 4, 2, MODE>(p, halo, rows, st);
+  else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
+  return true;
+}
+
+// bf16, N > 32: LDS-DMA kernel.  Tile by how many workgroups the layer yields (256 CUs).
+template <int MODE>
+bool dispatch_glds(const ConvParams& p, hipStream_t st) {
+  static const int force = []() {
+    const char* e = getenv("KD6D_CONV_TILE");   // tuning aid: 0 = old kernel, 1 = 128x128, 2 = 128x64, 3 = 64x64
+    return e ? atoi(e) : -1;
+  }();
+  if (force <= 0 || p.N <= 32) return false;      // measured: on par with / behind the register-staged kernel
+  const int N = p.N, M = p.M;
+  auto nblocks = [&](int bp, int bc) { return ((M + bp - 1) / bp) * ((N + bc - 1) / bc); };
+  int pick;
+  if (N > 64 && nblocks(128, 128) >= 384) pick = 1;
+  else if (nblocks(128, 64) >= 256) pick = 2;
+  else pick = 3;
+  if (force > 0) pick = force;
+  if (pick == 1) launch_glds<128, 128, 2, 2, MODE, 3>(p, st);
+  else if (pick == 2) launch_glds<128, 64, 2, 2, MODE, 3>(p, st);
+  else launch_glds<64, 64, 2, 2, MODE, 4>(p, st);
+  return true;
+}
+
 template <typename T, int MODE>
 void dispatch_igemm(const ConvParams& p, hipStream_t st) {
   const int N = p.N, M = p.M;
@@ -963,7 +1588,7 @@ void dispatch_wgrad(const WgradParams& p, hipStream_t st) {
 extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
                                void* y, const float* ch_scale, const float* ch_shift, int act,
                                const void* residual, const float* seg_scale, int out_f32,
-                               void* stream) {
+                               float* stats, int stats_groups, void* stream) {
   int rc = check_geom(g, dtype, "kd6d_conv2d_fwd");
   if (rc) return rc;
   KD6D_CHECK_ARG(x && w && y, "kd6d_conv2d_fwd: null tensor pointer");
@@ -977,9 +1602,22 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
   p.src = x; p.wgt = w; p.dst = y;
   p.ch_scale = ch_scale; p.ch_shift = ch_shift; p.residual = residual; p.seg_scale = seg_scale;
   p.act = act; p.out_f32 = out_f32 ? 1 : 0;
+  if (stats) {
+    KD6D_CHECK_ARG(g->cout % 4 == 0 && stats_groups >= 0, "kd6d_conv2d_fwd: fused statistics need cout %% 4 == 0");
+    KD6D_CHECK_ARG(stats_groups == 0 || (g->cout % stats_groups == 0 && (g->cout / stats_groups) % 4 == 0 &&
+                                         g->cout / stats_groups <= 8),
+                   "kd6d_conv2d_fwd: fused group statistics need 4 or 8 channels per group (cout=%d, groups=%d)",
+                   g->cout, stats_groups);
+    p.stats = stats; p.stats_groups = stats_groups;
+    if (stats_groups > 0) p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
+    for (int s = 0; s < g->nseg; ++s) p.seg_inv_hw[s] = 1.0f / (float)(p.seg[s].dst_hw);
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == KD6D_BF16) dispatch_igemm<bf16_t, MODE_FWD>(p, st);
-  else dispatch_igemm<float, MODE_FWD>(p, st);
+  if (dtype == KD6D_BF16) {
+    if (!dispatch_halo<MODE_FWD>(p, g, st) && !dispatch_glds<MODE_FWD>(p, st)) dispatch_igemm<bf16_t, MODE_FWD>(p, st);
+  } else {
+    dispatch_igemm<float, MODE_FWD>(p, st);
+  }
   KD6D_CHECK_LAUNCH("kd6d_conv2d_fwd");
   return KD6D_OK;
 }
@@ -1001,14 +1639,19 @@ extern "C" int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void*
   p.residual = accumulate ? dx : nullptr;
   p.act = KD6D_ACT_NONE; p.out_f32 = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == KD6D_BF16) dispatch_igemm<bf16_t, MODE_DGRAD>(p, st);
-  else dispatch_igemm<float, MODE_DGRAD>(p, st);
+  if (dtype == KD6D_BF16) {
+    if (!dispatch_halo<MODE_DGRAD>(p, g, st) && !dispatch_glds<MODE_DGRAD>(p, st)) dispatch_igemm<bf16_t, MODE_DGRAD>(p, st);
+  } else {
+    dispatch_igemm<float, MODE_DGRAD>(p, st);
+  }
   KD6D_CHECK_LAUNCH("kd6d_conv2d_dgrad");
   return KD6D_OK;
 }
 
+extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum, float* sumsq, void* stream);
+
 extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy,
-                                 float* dw, void* stream) {
+                                 float* dw, float* dbias, void* stream) {
   int rc = check_geom(g, dtype, "kd6d_conv2d_wgrad");
   if (rc) return rc;
   KD6D_CHECK_ARG(x && dy && dw, "kd6d_conv2d_wgrad: null tensor pointer");
@@ -1023,10 +1666,17 @@ extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void*
   for (int s = 0; s < g->nseg; ++s)
     KD6D_CHECK_ARG(p.seg[s].dst_row0 == p.seg[s].m_begin,
                    "kd6d_conv2d_wgrad: output levels must be packed back to back");
-  p.x = x; p.dy = dy; p.dw = dw;
+  p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == KD6D_BF16) dispatch_wgrad_tr(p, st);
-  else dispatch_wgrad<float>(p, st);
+  if (dtype == KD6D_BF16) {
+    dispatch_wgrad_tr(p, st);
+  } else {
+    dispatch_wgrad<float>(p, st);
+    if (dbias) {           // exact-fp32 parity path: separate column-sum pass
+      rc = kd6d_colstats(dtype, dy, p.M, g->cout, dbias, nullptr, stream);
+      if (rc) return rc;
+    }
+  }
   KD6D_CHECK_LAUNCH("kd6d_conv2d_wgrad");
   return KD6D_OK;
 }

@@ -775,7 +775,7 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, cons
 
 extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host,
                                 int nseg, int batch, int C, int groups, const float* gamma,
-                                const float* beta, float eps, float* stats, void* stream) {
+                                const float* beta, float eps, float* stats, int flags, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_gn_relu_fwd");
   if (rc) return rc;
   GnGeom gm;
@@ -787,12 +787,15 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, co
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
   KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_fwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
-  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
+  const bool ready = flags & KD6D_GN_STATS_READY;
+  if (!ready && !(flags & KD6D_GN_WS_ZEROED) &&
+      hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
     kd6d_set_error("kd6d_gn_relu_fwd: memset failed");
     return KD6D_ERR_LAUNCH;
   }
   DISPATCH_TTX(dtype, x_f32, {
-    hipLaunchKernelGGL((gn_stats_kernel<T_, TX_>), dim3(gm.nblk), dim3(kThreads), 0, st, (const TX_*)x, gm, stats);
+    if (!ready)
+      hipLaunchKernelGGL((gn_stats_kernel<T_, TX_>), dim3(gm.nblk), dim3(kThreads), 0, st, (const TX_*)x, gm, stats);
     hipLaunchKernelGGL((gn_relu_fwd_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x, (T_*)y, gm,
                        ngran, eps, stats, gamma, beta);
   });
@@ -803,7 +806,7 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, co
 extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx,
                                 const int32_t* level_hw_host, int nseg, int batch, int C, int groups,
                                 const float* gamma, const float* beta, float eps, const float* stats,
-                                float* gsum_ws, float* dgamma, float* dbeta, void* stream) {
+                                float* gsum_ws, float* dgamma, float* dbeta, int flags, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_gn_relu_bwd");
   if (rc) return rc;
   GnGeom gm;
@@ -816,7 +819,8 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
   const int nb = grid_for((ngran + 3) / 4);
   const size_t lds = (size_t)2 * C * sizeof(float);
   KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_bwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
-  if (hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
+  if (!(flags & KD6D_GN_WS_ZEROED) &&
+      hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
     kd6d_set_error("kd6d_gn_relu_bwd: memset failed");
     return KD6D_ERR_LAUNCH;
   }

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libkd6d.so")
 KD6D_BF16 = 0
 KD6D_F32 = 1
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+GN_STATS_READY, GN_WS_ZEROED = 1, 2
 MAX_SEG = 5
 ABI_VERSION = 2
 
@@ -51,17 +52,17 @@ _D = ctypes.c_double
 SIGNATURES = {
     "kd6d_abi_version": [],
     "kd6d_device_cu_count": [],
-    "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
-    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P],
+    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _P],
     "kd6d_pack_dgrad_weights": [_I, _P, _P, _P, _I, _I, _P],
     "kd6d_colstats": [_I, _P, _I64, _I, _P, _P, _P],
     "kd6d_bn_train_fwd": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     "kd6d_bn_train_bwd_reduce": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "kd6d_bn_train_bwd_apply": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
-    "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _P],
+    "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P,
-                         _P, _P, _P, _P],
+                         _P, _P, _P, _I, _P],
     "kd6d_maxpool2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
     "kd6d_maxpool2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kd6d_upsample2_add": [_I, _P, _P, _P, _I, _I, _I, _I, _P],

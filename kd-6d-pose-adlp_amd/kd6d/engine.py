@@ -170,20 +170,20 @@ class Conv:
         return 2 * g.rows_out * self.cout * self.k * self.k * self.cin
 
     def fwd(self, x, batch, levels, out=None, scale=None, shift=None, act=ACT_NONE, residual=None,
-            seg_scale=None, out_f32=False):
+            seg_scale=None, out_f32=False, stats=None, stats_groups=0):
         g = self.geom(batch, levels)
         if shift is None:
             shift = self.bias()
         return ops.conv2d_fwd(g, x, self.weight(), out=out, ch_scale=scale, ch_shift=shift, act=act,
-                              residual=residual, seg_scale=seg_scale, out_f32=out_f32, flops=self.flops(g)), g
+                              residual=residual, seg_scale=seg_scale, out_f32=out_f32, flops=self.flops(g),
+                              stats=stats, stats_groups=stats_groups), g
 
     def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False):
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
         st = self.net.store
         g = self.geom(batch, levels)
-        ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g))
-        if self.b is not None:
-            ops.colstats(dy, st.storage(self.b, "grads"))
+        ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
+                         dbias=None if self.b is None else st.storage(self.b, "grads"))
         if not need_dx:
             return None
         return ops.conv2d_dgrad(g, dy, self.weight_t(), dx=dx, accumulate=accumulate, flops=self.flops(g))
@@ -213,6 +213,7 @@ class BatchNorm:
 
 class ConvBlock:
     """conv(no bias) + BN + LeakyReLU(0.1)  (backbone/common.py:250-324)."""
+    FUSE_STATS_MAX_ROWS = 1 << 15      # up to 256 workgroups adding into one channel; beyond that a separate pass wins
 
     def __init__(self, net, name, cin, cout, k, stride=1):
         self.net, self.name = net, name
@@ -228,13 +229,18 @@ class ConvBlock:
     def fwd_train(self, x, batch, levels, tape):
         net, st = self.net, self.net.store
         # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
-        raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
-                               out=net.buf(self.name + ".raw", (self.conv.geom(batch, levels).rows_out, self.conv.cout_p),
-                                           torch.float32))
         c = self.conv.cout_p
         s = net.scratch(self.name, 6 * c)
         ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
-        ops.colstats(raw, ssum, ssq)
+        geom = self.conv.geom(batch, levels)
+        # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
+        # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
+        fused = geom.rows_out <= self.FUSE_STATS_MAX_ROWS
+        raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
+                               out=net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32),
+                               stats=s[0:2 * c] if fused else None, stats_groups=0)
+        if not fused:
+            ops.colstats(raw, ssum, ssq)
         z = net.buf(self.name + ".z", raw.shape, net.dtype)
         ops.bn_train_fwd(raw, z, ssum, ssq, st.storage(self.bn.gamma), st.storage(self.bn.beta), 1e-5, 0.1,
                          st.storage(self.bn.rm), st.storage(self.bn.rv), mean, invstd, ACT_LEAKY)
@@ -260,22 +266,28 @@ class GroupNormReLU:
         self.gamma = st.add(name + ".weight", "vec", (c,), (c,), True)
         self.beta = st.add(name + ".bias", "vec", (c,), (c,), True)
 
+    def stats(self, batch, levels):
+        """{sum, sumsq} per (level, image, group) in the per-step zeroed scratch arena; filled by the
+        epilogue of the conv that produces this layer's input."""
+        return self.net.scratch(self.name + ".stats", len(levels) * batch * self.groups * 2)
+
     def fwd(self, x, batch, levels, out=None):
         net, st = self.net, self.net.store
         hw = [h * w for (h, w) in levels]
-        stats = net.buf(self.name + ".stats", (len(levels) * batch * self.groups * 2,), torch.float32)
         if out is None:
             out = net.buf(self.name + ".y", x.shape)
-        ops.gn_relu_fwd(x, out, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), 1e-5, stats)
+        ops.gn_relu_fwd(x, out, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), 1e-5,
+                        self.stats(batch, levels), flags=ops.GN_STATS_READY)
         return out
 
     def bwd(self, x, dz, batch, levels, dx):
         net, st = self.net, self.net.store
         hw = [h * w for (h, w) in levels]
-        stats = net.buf(self.name + ".stats", (len(levels) * batch * self.groups * 2,), torch.float32)
-        gsum = net.buf(self.name + ".gsum", stats.shape, torch.float32)
+        stats = self.stats(batch, levels)
+        gsum = net.scratch(self.name + ".gsum", stats.numel())
         ops.gn_relu_bwd(x, dz, dx, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), stats,
-                        gsum, st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"))
+                        gsum, st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"),
+                        flags=ops.GN_WS_ZEROED)
         return dx
 
 
@@ -497,6 +509,8 @@ class PoseNet:
         B, _, H, W = images.shape
         self.prepare_weights(need_dgrad=self.training)
         self.tape = []
+        if self.scratch_buf is not None:
+            self.scratch_buf.zero_()         # one memset per step: every atomically accumulated statistic lives here
         x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=self.buf("input", (B * H * W, 8)))
         feats = self._backbone53(x, B, [(H, W)]) if self.arch == "darknet53" else self._backbone_tiny(x, B, [(H, W)])
         oc = self.out_channel
@@ -544,7 +558,8 @@ class PoseNet:
             saved = []
             for li, (conv, gn) in enumerate(tower):
                 raw, _ = conv.fwd(x, B, levels_all, out_f32=True,
-                                  out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32))
+                                  out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32),
+                                  stats=gn.stats(B, levels_all), stats_groups=gn.groups)
                 y = gn.fwd(raw, B, levels_all, out=self.buf("%s.act%d" % (tname, li), (r, oc)))
                 saved.append((x, raw))
                 x = y

@@ -172,8 +172,6 @@ class PoseModuleKD(nn.Module):
         if self.training:
             st = net.store
             st.ensure_grads()
-            if net.scratch_buf is not None:
-                net.scratch_buf.zero_()
             cls, reg = net.forward(x)
             tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
             teacher = pred_t if isinstance(pred_t, TeacherKnowledge) else None

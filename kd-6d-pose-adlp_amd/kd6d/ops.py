@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvGeom, check, lib  # noqa: F401
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, GN_STATS_READY, GN_WS_ZEROED, ConvGeom, check, lib  # noqa: F401
 
 
 def dt_code(dtype):
@@ -97,7 +97,7 @@ class Geom:
 
 
 def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE, residual=None,
-               seg_scale=None, out_f32=False, flops=0):
+               seg_scale=None, out_f32=False, flops=0, stats=None, stats_groups=0):
     assert x.shape == (geom.rows_in, geom.cin), (x.shape, geom.rows_in, geom.cin)
     assert w.dtype == x.dtype and w.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     odt = torch.float32 if out_f32 else x.dtype
@@ -112,7 +112,7 @@ def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE,
     with _Timed("conv_fwd", flops, geom):
         check(lib.kd6d_conv2d_fwd(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(out), _ptr(ch_scale),
                                   _ptr(ch_shift), act, _ptr(residual), _ptr(seg_scale), int(out_f32),
-                                  _stream()), "kd6d_conv2d_fwd")
+                                  _ptr(stats), int(stats_groups), _stream()), "kd6d_conv2d_fwd")
     return out
 
 
@@ -129,12 +129,13 @@ def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     return dx
 
 
-def conv2d_wgrad(geom, x, dy, dw, flops=0):
+def conv2d_wgrad(geom, x, dy, dw, flops=0, dbias=None):
     assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
     assert x.dtype == dy.dtype and dw.dtype == torch.float32
     assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     with _Timed("conv_wgrad", flops, geom):
-        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _stream()),
+        assert dbias is None or (dbias.dtype == torch.float32 and dbias.numel() >= geom.cout)
+        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), _stream()),
               "kd6d_conv2d_wgrad")
     return dw
 
@@ -184,22 +185,22 @@ def _hw_array(level_hw):
     return arr
 
 
-def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats):
+def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats, flags=0):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
     assert stats.numel() >= len(level_hw) * batch * groups * 2
     check(lib.kd6d_gn_relu_fwd(dt_code(y.dtype), _xf32(x, y.dtype), _ptr(x), _ptr(y), _hw_array(level_hw), len(level_hw),
-                               batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats), _stream()),
+                               batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats), flags, _stream()),
           "kd6d_gn_relu_fwd")
     return y
 
 
-def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta, eps=1e-5):
+def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta, eps=1e-5, flags=0):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
     check(lib.kd6d_gn_relu_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
                                len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats),
-                               _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), _stream()), "kd6d_gn_relu_bwd")
+                               _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), flags, _stream()), "kd6d_gn_relu_bwd")
     return dx
 
 

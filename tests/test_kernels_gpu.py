@@ -41,6 +41,10 @@ CONV_CASES = [
     (2, 128, 16, 3, 1, [(8, 8), (4, 4), (2, 2), (1, 1)]),
     (1, 256, 512, 3, 2, [(6, 6)]),
     (2, 8, 32, 3, 1, [(40, 40)]),                      # exercises the 256-pixel tiles
+    # 3x3/s1 with C % 64 == 0: the halo-patch kernel (several tiles, levels sharing a tile, N tail, 3 chunks)
+    (2, 128, 256, 3, 1, [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]),
+    (1, 64, 240, 3, 1, [(64, 64)]),
+    (3, 192, 64, 3, 1, [(5, 7), (3, 2)]),
 ]
 
 
@@ -136,14 +140,62 @@ def test_conv_wgrad(gpu_device, dtype, case):
     dys = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
     dev = gpu_device
     dw = torch.zeros(Cout, k, k, Cin, dtype=torch.float32, device=dev)
-    ops.conv2d_wgrad(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), dw)
+    db = torch.full((Cout,), 0.5, dtype=torch.float32, device=dev)      # running sum: the call accumulates
+    ops.conv2d_wgrad(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), dw, dbias=db)
     torch.cuda.synchronize()
     ref = torch.zeros(Cout, Cin, k, k)
+    ref_b = torch.full((Cout,), 0.5, dtype=torch.float64)
     for x, dy in zip(xs, dys):
         ref += torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=stride, padding=pad)
+        ref_b += dy.double().sum(dim=(0, 2, 3))
     got = dw.cpu().permute(0, 3, 1, 2)
     scale = float(ref.abs().max())
     torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4 * max(scale, 1.0))
+    torch.testing.assert_close(db.cpu().double(), ref_b, rtol=2e-4, atol=2e-4 * max(float(ref_b.abs().max()), 1.0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # (B, Cin, Cout, k, stride, levels, groups)   groups 0 = per-channel (BatchNorm) statistics
+    (2, 8, 16, 3, 1, [(12, 10)], 0),
+    (3, 32, 64, 3, 2, [(16, 16)], 0),
+    (2, 16, 256, 1, 1, [(9, 9)], 0),
+    (3, 128, 128, 3, 1, [(8, 8), (4, 4), (2, 2), (1, 1)], 32),      # 4 channels per group, tiny levels
+    (2, 64, 256, 3, 1, [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)], 32),   # 8 per group, halo kernel
+    (5, 128, 256, 3, 1, [(3, 3)], 32),                              # fragments straddle images
+])
+def test_conv_fwd_fused_statistics(gpu_device, dtype, case):
+    """Statistics accumulated by the conv epilogue == sums over the stored fp32 output
+    (what kd6d_colstats / the GroupNorm reduction pass would produce)."""
+    ops = _ops()
+    B, Cin, Cout, k, stride, levels, groups = case
+    g = torch.Generator().manual_seed(17 + Cout)
+    pad = k // 2
+    xs = [round_to(torch.randn(B, Cin, h, w, generator=g), dtype) for (h, w) in levels]
+    w = round_to(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, dtype)
+    bias = torch.randn(Cout, generator=g)
+    geom = ops.Geom(B, Cin, Cout, k, stride, pad, levels)
+    dev = gpu_device
+    n_stats = 2 * Cout if groups == 0 else len(levels) * B * groups * 2
+    stats = torch.zeros(n_stats, device=dev)
+    y = ops.conv2d_fwd(geom, pack_levels(xs, dtype).to(dev), w_to_krsc(w, dtype).to(dev), ch_shift=bias.to(dev),
+                       out_f32=True, stats=stats, stats_groups=groups)
+    torch.cuda.synchronize()
+    got_y = unpack_levels(y.cpu(), B, geom.levels_out)
+    st = stats.cpu().double()
+    if groups == 0:
+        s1 = sum(t.double().sum(dim=(0, 2, 3)) for t in got_y)
+        s2 = sum((t.double() ** 2).sum(dim=(0, 2, 3)) for t in got_y)
+        ref = torch.cat([s1, s2])
+    else:
+        parts = []
+        for t in got_y:                       # (B, C, h, w) -> (B, G, cpg*h*w)
+            tg = t.double().reshape(B, groups, -1)
+            parts.append(torch.stack([tg.sum(-1), (tg ** 2).sum(-1)], dim=-1).reshape(-1))
+        ref = torch.cat(parts)
+    torch.testing.assert_close(st, ref, rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0))
+    for x, gl in zip(xs, got_y):              # and the output itself is unchanged by the statistics pass
+        torch.testing.assert_close(gl, F.conv2d(x, w, bias, stride=stride, padding=pad), **_tol(dtype, stored=False))
 
 
 def test_pack_dgrad_weights(gpu_device):
@@ -253,7 +305,7 @@ def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C):
     stats = torch.empty(len(levels) * B * G * 2, device=dev)
     gsum = torch.empty_like(stats)
     dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
-    ops.gn_relu_fwd(xp, y, hw, B, G, gamma.to(dev), beta.to(dev), 1e-5, stats)
+    ops.gn_relu_fwd(xp, y, hw, B, G, gamma.to(dev), beta.to(dev), 1e-5, stats)     # flags=0: reduces + zeroes itself
     ops.gn_relu_bwd(xp, dzp, dx, hw, B, G, gamma.to(dev), beta.to(dev), stats, gsum, dgam, dbet)
     torch.cuda.synchronize()
     tol = _tol(dtype, stored=True)

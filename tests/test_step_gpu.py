@@ -155,7 +155,9 @@ def test_step_against_reference_golden(gpu_device, name, precision):
     print("[%s %s] grad-norm deviation: worst %.4f (%s) weighted-mean %.5f total %.5f" % (
         name, precision, worst, max(dev_, key=dev_.get), wmean, abs(total - gn_ref) / gn_ref))
     if precision == "fp32":
-        assert worst <= 1e-2, "worst per-parameter grad-norm deviation %.4f" % worst
+        # per-tensor worst case: a tiny-norm BN gain whose gradient is a cancelling sum; its value moves with
+        # the order of the fp32 atomics (observed 0.1 % .. 1.3 % run to run), the norm-weighted mean does not
+        assert worst <= 2e-2 and wmean <= 1e-3, "per-parameter grad-norm deviation worst %.4f mean %.5f" % (worst, wmean)
         assert total == pytest.approx(gn_ref, rel=1e-2)
     else:
         assert worst <= 0.5 and wmean <= 6e-2, (worst, wmean)

@@ -65,7 +65,19 @@ STUDENT = [
 ]
 
 
+EAGER = False
+
+
 def timeit(fn, iters):
+    if EAGER:           # for rocprofv3 counter runs: plain launches
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return 0.0
+    return timeit_graph(fn, iters)
+
+
+def timeit_graph(fn, iters):
     """`iters` launches captured in one hipGraph (no host launch cost between them), replayed 3x."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -98,7 +110,11 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--batch", type=int, default=B)
     ap.add_argument("--only", default="")
+    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--stats", type=int, default=-1, help="fwd: fused statistics (0 = per channel, G = groups), fp32 output")
     a = ap.parse_args()
+    global EAGER
+    EAGER = a.eager
     dev = torch.device("cuda:0")
     shapes = (TEACHER if a.set in ("teacher", "all") else []) + (STUDENT if a.set in ("student", "all") else [])
     kinds = ["fwd", "dgrad", "wgrad"] if a.kind == "all" else [a.kind]
@@ -119,14 +135,20 @@ def main():
         for kind in kinds:
             if name.startswith("t.") and kind != "fwd":
                 continue
-            if kind == "fwd":
+            if kind == "fwd" and a.stats >= 0:
+                yf = torch.empty(geom.rows_out, cout, dtype=torch.float32, device=dev)
+                st = torch.zeros(max(2 * cout, len(levels) * a.batch * max(a.stats, 1) * 2), device=dev)
+                us0 = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=yf, out_f32=True), a.iters)
+                us = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=yf, out_f32=True, stats=st, stats_groups=a.stats), a.iters)
+                name = name + " (f32 out %.1f us; +stats)" % us0
+            elif kind == "fwd":
                 us = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=y), a.iters)
             elif kind == "dgrad":
                 us = timeit(lambda: ops.conv2d_dgrad(geom, dy, w, dx=dx), a.iters)
             else:
                 us = timeit(lambda: ops.conv2d_wgrad(geom, x, dy, dw), a.iters)
             print("| %s | %s | %d | %d | %d | %.2f | %.1f | %.0f |" % (name, kind, geom.rows_out, cout, k * k * cin,
-                                                                      flop / 1e9, us, flop / us / 1e6))
+                                                                      flop / 1e9, us, flop / max(us, 1e-9) / 1e6))
 
 
 if __name__ == "__main__":
