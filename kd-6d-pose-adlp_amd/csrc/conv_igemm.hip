@@ -45,6 +45,8 @@ struct ConvParams {
   int K;       // ks*ks*C
   int M;       // total destination pixels
   int n_ctiles;
+  int n_ptiles;
+  int p_fastest;   // workgroup order: pixel tiles fastest (weight tile shared inside an XCD) instead of channel tiles
   SegDev seg[kMaxSeg];
   const void* src;
   const void* wgt;
@@ -392,8 +394,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int wc = wave / WP;
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_c = wg % p.n_ctiles;
-  const int tile_p = wg / p.n_ctiles;
+  const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
+  const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
   const int n0 = tile_c * BC;
 
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   constexpr int L = PR + CR;    // LDS-DMA instructions per wave per k-step
   constexpr int STAGE = (BP + BC) * 128;
   static_assert(WP * WC == 4 && BP % 32 == 0 && BC % 32 == 0 && PI >= 1 && CI >= 1, "tile shape");
-  static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
   static_assert((NSTAGE - 2) * L <= 63, "vmcnt range");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -570,8 +572,8 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   const int wc = wave / WP;
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_c = wg % p.n_ctiles;
-  const int tile_p = wg / p.n_ctiles;
+  const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
+  const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
   const int n0 = tile_c * BC;
 
@@ -678,9 +680,14 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // retire this k-step's loads, keep the younger stages in flight
-    if (NSTAGE == 4 && kt + 2 < nk) wait_vmcnt<(NSTAGE - 2) * L>();
-    else if (kt + 1 < nk) wait_vmcnt<L>();
-    else wait_vmcnt<0>();
+    {
+      const int younger = nk - 1 - kt;          // k-steps issued after this one (capped by the ring)
+      if (NSTAGE >= 6 && younger >= 4) wait_vmcnt<(NSTAGE >= 6 ? 4 : 0) * L>();
+      else if (NSTAGE >= 5 && younger >= 3) wait_vmcnt<(NSTAGE >= 5 ? 3 : 0) * L>();
+      else if (NSTAGE >= 4 && younger >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 : 0) * L>();
+      else if (younger >= 1) wait_vmcnt<L>();
+      else wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     if (kt + NSTAGE - 1 < nk) {
       int st2 = stage + NSTAGE - 1;
@@ -747,8 +754,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvPar
   const int wc = wave / WP;
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_c = wg % p.n_ctiles;
-  const int tile_p = wg / p.n_ctiles;
+  const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
+  const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
   const int n0 = tile_c * BC;
   const int patch_lo = m0 - halo;
@@ -1381,11 +1388,37 @@ int check_geom(const kd6d_conv_geom* g, int dtype, const char* who) {
   return KD6D_OK;
 }
 
+// Workgroup order.  After the XCD remap an XCD runs a CONTIGUOUS range of ~1/8 of the tile ids, so the
+// fastest-varying tile index decides which operand that XCD's 4 MiB L2 can keep: channel tiles fastest
+// -> the XCD touches few pixel tiles but ALL weights; pixel tiles fastest -> few weight tiles but many
+// pixels.  Pick the order with the smaller per-XCD footprint (small-M / wide-N layers: weights).
+void set_tile_order(ConvParams& q, int ptiles, int BP, int BC) {
+  q.n_ptiles = ptiles;
+  static const int force = []() {
+    const char* e = getenv("KD6D_CONV_ORDER");
+    return e ? atoi(e) : -1;
+  }();
+  const double tiles = (double)ptiles * q.n_ctiles;
+  const double per_xcd = tiles / 8.0;
+  const double w_tile = (double)BC * q.K * 2.0, x_tile = (double)BP * q.C * 2.0 * (q.ks > 1 ? 1.5 : 1.0);
+  // channel tiles fastest: an XCD spans per_xcd / n_ctiles pixel tiles (>= 1) and min(per_xcd, n_ctiles) weight tiles
+  auto foot = [&](double n_fast, double t_fast, double t_slow) {
+    const double fast = per_xcd < n_fast ? per_xcd : n_fast;
+    const double slow = per_xcd / n_fast < 1.0 ? 1.0 : per_xcd / n_fast;
+    return fast * t_fast + slow * t_slow;
+  };
+  const double c_fast = foot(q.n_ctiles, w_tile, x_tile);
+  const double p_fast = foot(ptiles, x_tile, w_tile);
+  q.p_fastest = p_fast < c_fast ? 1 : 0;
+  if (force >= 0) q.p_fastest = force;
+}
+
 template <typename T, int BP, int BC, int WP, int WC, int MODE>
 void launch_igemm(const ConvParams& p, hipStream_t st) {
   ConvParams q = p;
   q.n_ctiles = (p.N + BC - 1) / BC;
   const int ptiles = (p.M + BP - 1) / BP;
+  set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)(BP + BC) * 128 * 2;
   auto kern = conv_igemm_kernel<T, BP, BC, WP, WC, MODE>;
   static bool attr_set = false;
@@ -1402,6 +1435,7 @@ void launch_glds(const ConvParams& p, hipStream_t st) {
   ConvParams q = p;
   q.n_ctiles = (p.N + BC - 1) / BC;
   const int ptiles = (p.M + BP - 1) / BP;
+  set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)(BP + BC) * 128 * NSTAGE;
   auto kern = conv_igemm_glds_kernel<BP, BC, WP, WC, MODE, NSTAGE>;
   static bool attr_set = false;
@@ -1421,6 +1455,7 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
   ConvParams q = p;
   q.n_ctiles = (p.N + BC - 1) / BC;
   const int ptiles = (p.M + BP - 1) / BP;
+  set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)2 * PL * NW * 1024 + (size_t)3 * BC * 128;
   auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE>;
   static bool attr_set = false;
@@ -1471,17 +1506,20 @@ bool dispatch_glds(const ConvParams& p, hipStream_t st) {
     const char* e = getenv("KD6D_CONV_TILE");   // tuning aid: 0 = old kernel, 1 = 128x128, 2 = 128x64, 3 = 64x64
     return e ? atoi(e) : -1;
   }();
-  if (force <= 0 || p.N <= 32) return false;      // measured: on par with / behind the register-staged kernel
+  if (force == 0 || p.N <= 32) return false;
   const int N = p.N, M = p.M;
   auto nblocks = [&](int bp, int bc) { return ((M + bp - 1) / bp) * ((N + bc - 1) / bc); };
-  int pick;
-  if (N > 64 && nblocks(128, 128) >= 384) pick = 1;
-  else if (nblocks(128, 64) >= 256) pick = 2;
-  else pick = 3;
+  // measured (tools/bench_conv.py): with enough workgroups the register-staged kernel is as fast or faster
+  // (several workgroups per CU hide the load round trip); the layers with <= ~1 workgroup per CU and a long
+  // K (teacher stages 4/5, FPN top) are bound by that round trip and gain from a deep LDS-DMA ring
+  int pick = 0;
+  if (nblocks(128, 64) < 384) pick = 3;
   if (force > 0) pick = force;
+  if (pick == 0) return false;
   if (pick == 1) launch_glds<128, 128, 2, 2, MODE, 3>(p, st);
   else if (pick == 2) launch_glds<128, 64, 2, 2, MODE, 3>(p, st);
-  else launch_glds<64, 64, 2, 2, MODE, 4>(p, st);
+  else if (pick == 3) launch_glds<64, 64, 2, 2, MODE, 4>(p, st);
+  else launch_glds<64, 64, 2, 2, MODE, 6>(p, st);
   return true;
 }
 

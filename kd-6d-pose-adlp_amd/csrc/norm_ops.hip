@@ -17,16 +17,42 @@ constexpr int kThreads = 256;
 // Per-channel reductions over rows.  Thread t owns channel granule t % (C/EG);
 // requires (C/EG) | 256.  F(acc, granule index, values...) accumulates NACC sums.
 // ---------------------------------------------------------------------------
+// v += v of the lanes o to the right (mod 16) inside each DPP row of 16 lanes: VALU only.
+template <int O>
+__device__ __forceinline__ float row_ror_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + O, 0xF, 0xF, true));
+}
+
 template <int NACC, int EG>
 __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int C, int cg,
                                                     float* const* out) {
   extern __shared__ float red[];  // NACC * C floats
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) red[i] = 0.f;
   __syncthreads();
+  // narrow tensors (C/EG < 16): the lanes of a 16-lane row that own the same channel granule are summed
+  // with DPP rotations first, so an LDS address sees 16 adds per workgroup instead of up to 256
+  // (same-address LDS float atomics serialise)
+  const int cgs = C / EG;
+  const bool pre = cgs < 16 && (16 % cgs) == 0;
+  if (pre) {
 #pragma unroll
-  for (int a = 0; a < NACC; ++a)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-    for (int e = 0; e < EG; ++e) atomicAdd(&red[a * C + cg * EG + e], acc[a][e]);
+      for (int e = 0; e < EG; ++e) {
+        float v = acc[a][e];
+        v = row_ror_add<8>(v);
+        if (cgs <= 4) v = row_ror_add<4>(v);
+        if (cgs <= 2) v = row_ror_add<2>(v);
+        if (cgs <= 1) v = row_ror_add<1>(v);
+        acc[a][e] = v;
+      }
+  }
+  if (!pre || (int)(threadIdx.x & 15) < cgs) {
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int e = 0; e < EG; ++e) atomicAdd(&red[a * C + cg * EG + e], acc[a][e]);
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
     const int a = i / C, c = i - a * C;
@@ -49,6 +75,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const T* __restrict_
   for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
   const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   if (rsub < rpp) {
+#pragma unroll 4
     for (long long r = (long long)blockIdx.x * rpp + rsub; r < rows; r += (long long)gridDim.x * rpp) {
       float v[EG];
       granule_to_f32<T>(xg[r * cgs + cg], v);
@@ -111,6 +138,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     }
   }
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+#pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float v[EG];
@@ -146,6 +174,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
 #pragma unroll
   for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
+#pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float xv[EG], dv[EG];
@@ -192,6 +221,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
   }
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
   u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+#pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float xv[EG], dv[EG];
@@ -266,6 +296,7 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict
   float a1[EG], a2[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+#pragma unroll 4
   for (long long g = threadIdx.x; g < ngran; g += kThreads) {
     float v[EG];
     load_x<TX, EG>(xb, g, v);
@@ -307,6 +338,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
 #pragma unroll
   for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+#pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     const long long row = g / cgs;
@@ -368,6 +400,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
   const TX* xb = x + base;
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz + base);
   const long long ngran = (long long)r_cnt * cgs;
+#pragma unroll 4
   for (long long g = threadIdx.x; g < ngran; g += kThreads) {
     float xv[EG], dv[EG];
     load_x<TX, EG>(xb, g, xv);
@@ -414,6 +447,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
   for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
   u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+#pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     const long long row = g / cgs;
@@ -597,6 +631,7 @@ __global__ __launch_bounds__(kThreads) void eltwise_kernel(const T* __restrict__
   const u32x4_t* xg = reinterpret_cast<const u32x4_t*>(x);
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dy);
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+#pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
        g += (long long)gridDim.x * kThreads) {
     float a[EG], d[EG];

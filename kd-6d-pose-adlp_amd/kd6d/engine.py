@@ -182,8 +182,18 @@ class Conv:
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
         st = self.net.store
         g = self.geom(batch, levels)
-        ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
-                         dbias=None if self.b is None else st.storage(self.b, "grads"))
+        side = self.net.side_stream
+        if side is None:
+            ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
+                             dbias=None if self.b is None else st.storage(self.b, "grads"))
+        else:
+            # the weight gradient feeds nothing in the reverse sweep: fork it onto the side stream so it
+            # overlaps the dgrad / normalisation chain (both under-fill 256 CUs at these layer sizes);
+            # PoseNet.backward joins before the gradient exchange.  x and dy are per-layer buffers.
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
+                                 dbias=None if self.b is None else st.storage(self.b, "grads"))
         if not need_dx:
             return None
         return ops.conv2d_dgrad(g, dy, self.weight_t(), dx=dx, accumulate=accumulate, flops=self.flops(g))
@@ -303,6 +313,7 @@ class PoseNet:
         self._bufs, self._scratch_off, self._scratch_size, self.scratch_buf = {}, {}, 0, None
         self.wt = None
         self.training = True
+        self.side_stream = None        # set (e.g. by GraphedKDStep) to run weight gradients concurrently
         feat, oc = BACKBONE_CFG[arch]
         self.out_channel = oc
         self.n_levels = 5 if arch == "darknet53" else 4
@@ -585,7 +596,7 @@ class PoseNet:
             for li in range(len(tower) - 1, -1, -1):
                 conv, gn = tower[li]
                 x_in, raw = saved[li]
-                draw = gn.bwd(raw, dx, B, lv_all, self.buf("%s.draw" % tname, (r, oc)))
+                draw = gn.bwd(raw, dx, B, lv_all, self.buf("%s.draw%d" % (tname, li), (r, oc)))
                 if li > 0:
                     dx = conv.bwd(x_in, draw, B, lv_all, dx=self.buf("%s.dact" % tname, (r, oc)))
                 else:
@@ -647,4 +658,6 @@ class PoseNet:
                 grad = blk.bwd(rec, grad, need_dx=need_dx,
                                dx=self.buf(blk.name + ".dx", rec[1].shape) if need_dx else None)
             i_rec -= 1
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
         return None

@@ -16,16 +16,18 @@ come from torch's graph-safe Philox generator.
 """
 import torch
 
-from .kd_losses import PackedTargets
+from .kd_losses import DeferredTeacher, PackedTargets
 from .libs import distributed as D
 from .libs.poses import ImageList
 
-_TARGET_FIELDS = ("mask", "kp3d", "K", "bbox_trans", "class_ids", "n_gt", "rot", "trans")
-
-
 class GraphedKDStep:
-    def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3):
+    def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3,
+                 concurrent=True):
         self.teacher, self.student, self.opt = teacher, student, optimizer
+        # fork/join inside the captured graph: the teacher's forward runs beside the student's, and the weight
+        # gradients beside the dgrad / normalisation chain (many of these kernels fill < 256 CUs on their own)
+        self.teacher_stream = torch.cuda.Stream() if concurrent else None
+        student.net.side_stream = torch.cuda.Stream() if concurrent else None
         self.w_cls, self.w_reg, self.w_kd = (float(w) for w in loss_weights)
         self.cfg_kd = cfg_kd
         self.warmup = warmup
@@ -36,7 +38,13 @@ class GraphedKDStep:
     def _forward_backward(self):
         self.student.zero_grad()
         with torch.no_grad():
-            pred_t = self.teacher(self.images, targets=self.tgt, is_teacher=True, cfg_kd=self.cfg_kd)
+            if self.teacher_stream is None:
+                pred_t = self.teacher(self.images, targets=self.tgt, is_teacher=True, cfg_kd=self.cfg_kd)
+            else:
+                self.teacher_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.teacher_stream):
+                    pred_t = self.teacher(self.images, targets=self.tgt, is_teacher=True, cfg_kd=self.cfg_kd)
+                pred_t = DeferredTeacher(pred_t, self.teacher_stream)
         _, ld = self.student(self.images, targets=self.tgt, pred_t=pred_t, cfg_kd=self.cfg_kd)
         loss = ld["loss_cls"] * self.w_cls + ld["loss_reg"] * self.w_reg
         if self.w_kd > 0.0:
@@ -48,12 +56,11 @@ class GraphedKDStep:
         x = images.tensors if hasattr(images, "tensors") else images
         if self.images is None:
             self.images = ImageList(torch.empty_like(x), getattr(images, "sizes", None))
-            self.tgt = tgt.clone_static() if hasattr(tgt, "clone_static") else _clone_targets(tgt)
+            self.tgt = tgt.clone_static()
         assert x.shape == self.images.tensors.shape, "the captured step has a static batch shape"
         assert (tgt.mask_h, tgt.mask_w) == (self.tgt.mask_h, self.tgt.mask_w)
         self.images.tensors.copy_(x, non_blocking=True)
-        for f in _TARGET_FIELDS:
-            getattr(self.tgt, f).copy_(getattr(tgt, f), non_blocking=True)
+        self.tgt.copy_from(tgt)
 
     def _snapshot(self):
         st, opt = self.student.net.store, self.opt
@@ -119,11 +126,3 @@ class GraphedKDStep:
         self.g_opt.replay()
         self._count_opt_step()
         return self.losses
-
-
-def _clone_targets(tgt):
-    out = object.__new__(PackedTargets)
-    out.__dict__.update(tgt.__dict__)
-    for f in _TARGET_FIELDS:
-        setattr(out, f, getattr(tgt, f).clone())
-    return out

@@ -63,6 +63,47 @@ class PackedTargets:
         self.rot = rot.to(device).contiguous()
         self.trans = tr.to(device).contiguous()
         self.frame_wh = (640.0, 480.0)        # kd_loss.py:116-117 ("not 256")
+        self._pack_small()
+
+    _SMALL_F = ("kp3d", "K", "bbox_trans", "rot", "trans")
+    _SMALL_I = ("class_ids", "n_gt")
+
+    def _pack_small(self):
+        """Re-home the small per-image fields as views of one fp32 and one int32 buffer, so that a static
+        (hipGraph) copy of a batch is 3 device copies (mask, floats, ints) instead of 8."""
+        for names, attr in ((self._SMALL_F, "flat_f"), (self._SMALL_I, "flat_i")):
+            parts = [getattr(self, n) for n in names]
+            sizes = [(p.numel() + 3) // 4 * 4 for p in parts]          # keep every view 16-byte aligned
+            flat = torch.zeros(sum(sizes), dtype=parts[0].dtype, device=parts[0].device)
+            off = 0
+            for n, p_, sz in zip(names, parts, sizes):
+                v = flat[off:off + p_.numel()].view(p_.shape)
+                v.copy_(p_)
+                setattr(self, n, v)
+                off += sz
+            setattr(self, attr, flat)
+
+    def clone_static(self):
+        out = object.__new__(PackedTargets)
+        out.__dict__.update(self.__dict__)
+        out.mask = self.mask.clone()
+        for names, attr in ((self._SMALL_F, "flat_f"), (self._SMALL_I, "flat_i")):
+            setattr(out, attr, getattr(self, attr).clone())
+        out._rebind()
+        return out
+
+    def _rebind(self):
+        for names, attr in ((self._SMALL_F, "flat_f"), (self._SMALL_I, "flat_i")):
+            flat, off = getattr(self, attr), 0
+            for n in names:
+                old = getattr(self, n)
+                setattr(self, n, flat[off:off + old.numel()].view(old.shape))
+                off += (old.numel() + 3) // 4 * 4
+
+    def copy_from(self, other):
+        self.mask.copy_(other.mask, non_blocking=True)
+        self.flat_f.copy_(other.flat_f, non_blocking=True)
+        self.flat_i.copy_(other.flat_i, non_blocking=True)
 
 
 class TeacherKnowledge(dict):
@@ -86,16 +127,28 @@ class TeacherKnowledge(dict):
         return dict.__getitem__(self, key)
 
 
+class DeferredTeacher:
+    """pred_t produced on another HIP stream (the frozen teacher's forward overlaps the student's).
+    The student's loss joins that stream right before it first reads the teacher's cells."""
+
+    def __init__(self, value, stream):
+        self.value, self.stream = value, stream
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return self.value
+
+
 def teacher_select(cls_t, reg_t, levels, batch, bbox_trans, th=0.1, positive_num=10, positive_lambda=1.0, cap=CAP,
                    frame_wh=(640.0, 480.0)):
     dev = cls_t.device
     lv = make_levels(batch, levels)
-    t_cnt = torch.zeros(batch, dtype=torch.int32, device=dev)
-    t_kp = torch.zeros(batch * cap, 8, 2, dtype=torch.float32, device=dev)
-    t_score = torch.zeros(batch * cap, 8, dtype=torch.float32, device=dev)
-    t_row = torch.zeros(batch * cap, dtype=torch.int32, device=dev)
-    t_kp_n = torch.zeros_like(t_kp)
-    t_beta = torch.zeros_like(t_score)
+    n = batch * cap
+    wf = torch.zeros(n * 48, dtype=torch.float32, device=dev)        # one fill for all fp32 outputs
+    wi = torch.zeros(n + (batch + 3) // 4 * 4, dtype=torch.int32, device=dev)
+    t_kp, t_kp_n = wf[0:n * 16].view(n, 8, 2), wf[n * 16:n * 32].view(n, 8, 2)
+    t_score, t_beta = wf[n * 32:n * 40].view(n, 8), wf[n * 40:n * 48].view(n, 8)
+    t_row, t_cnt = wi[0:n], wi[n:n + batch]
     check(lib.kd6d_teacher_select(ctypes.byref(lv), ops._ptr(cls_t), ops._ptr(reg_t), ops._ptr(bbox_trans),
                                   th, float(positive_num), float(positive_lambda), cap, frame_wh[0], frame_wh[1],
                                   ops._ptr(t_cnt), ops._ptr(t_kp), ops._ptr(t_score), ops._ptr(t_row),
@@ -144,33 +197,33 @@ class KDLoss:
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         labels = torch.empty(rows, **i32)
-        pos_cnt = torch.zeros(batch, **i32)
-        pos_row = torch.zeros(batch * cap, **i32)
-        pos_gt = torch.zeros(batch * cap, **i32)
+        n = batch * cap
+        bp = (batch + 3) // 4 * 4
+        # one zero fill per dtype for every per-step accumulator / slot array of the loss side
+        wf = torch.zeros(8 + bp + n * 64, **f32)
+        wi = torch.zeros(3 * bp + 4 + 2 * n, **i32)
+        pos_cnt, valid, s_start = wi[0:batch], wi[bp:bp + batch], wi[2 * bp:2 * bp + batch]
+        n_valid = wi[3 * bp:3 * bp + 1]
+        pos_row, pos_gt = wi[3 * bp + 4:3 * bp + 4 + n], wi[3 * bp + 4 + n:3 * bp + 4 + 2 * n]
         st = ops._stream()
         P = ops._ptr
         check(lib.kd6d_ssc_assign(ctypes.byref(lv), P(tgt.mask), tgt.mask_h, tgt.mask_w, P(tgt.kp3d), P(tgt.K),
                                   P(tgt.class_ids), P(tgt.n_gt), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
                                   P(keys), self.positive_num, self.positive_lambda, cap, P(labels), P(pos_cnt),
                                   P(pos_row), P(pos_gt), st), "kd6d_ssc_assign")
-        losses = torch.zeros(4, **f32)         # cls, reg, kd, (pad)
+        losses = wf[0:4]                       # cls, reg, kd, (pad)
+        loss_img = wf[8:8 + batch]
+        o = 8 + bp
+        xs, g_reg, g_xs = (wf[o + k * n * 16:o + (k + 1) * n * 16].view(n, 8, 2) for k in range(3))
+        alpha, g_alpha = (wf[o + n * 48 + k * n * 8:o + n * 48 + (k + 1) * n * 8].view(n, 8) for k in range(2))
         check(lib.kd6d_focal_fwd(P(cls_s), P(labels), rows, self.gamma, self.alpha, P(losses[0:1]), st),
               "kd6d_focal_fwd")
-        xs = torch.zeros(batch * cap, 8, 2, **f32)
-        alpha = torch.zeros(batch * cap, 8, **f32)
-        g_reg = torch.zeros(batch * cap, 8, 2, **f32)
-        s_start = torch.empty(batch, **i32)
         fw, fh = tgt.frame_wh
         check(lib.kd6d_student_points(ctypes.byref(lv), P(cls_s), P(reg_s), P(pos_cnt), P(pos_row), P(pos_gt),
                                       P(tgt.class_ids), P(tgt.kp3d), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
                                       P(self.diameters), self.kinv, fw, fh, cap, P(xs), P(alpha), P(g_reg),
                                       P(losses[1:2]), P(s_start), st), "kd6d_student_points")
-        n_valid = torch.zeros(1, **i32)
-        valid = torch.zeros(batch, **i32)
-        g_xs = torch.zeros_like(xs)
-        g_alpha = torch.zeros_like(alpha)
         if teacher is not None:
-            loss_img = torch.zeros(batch, **f32)
             check(lib.kd6d_sinkhorn_div_fwd_bwd(P(xs), P(alpha), P(s_start), P(pos_cnt), P(teacher.t_kp_norm),
                                                 P(teacher.t_beta), P(teacher.t_start), P(teacher.t_cnt), batch, self.p,
                                                 self.blur, self.scaling, self.reach, P(loss_img), P(valid),

@@ -174,6 +174,8 @@ class PoseModuleKD(nn.Module):
             st.ensure_grads()
             cls, reg = net.forward(x)
             tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
+            if isinstance(pred_t, kd_losses.DeferredTeacher):      # teacher ran concurrently on another stream
+                pred_t = pred_t.join()
             teacher = pred_t if isinstance(pred_t, TeacherKnowledge) else None
             if pred_t is not None and teacher is None:
                 raise TypeError("pred_t must come from a kd6d teacher forward (TeacherKnowledge)")
