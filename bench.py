@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--frame", type=str, default="crop256", choices=["crop256", "full640"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    p.add_argument("--no-pipeline", action="store_true",
+                   help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--layer-table", type=str, default="", help="write the per-launch conv table (instrumented steps) here")
     return p.parse_args()
@@ -120,15 +122,21 @@ def main():
         batches.append((images.to(dev), PackedTargets(targets, dev)))
 
     from kd6d.graph import GraphedKDStep
-    gstep = None if args.no_graph else GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0))
+    gstep = None if args.no_graph else GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0),
+                                                     pipeline=not args.no_pipeline)
+    if gstep is not None and gstep.pipeline:
+        gstep(*batches[0])          # priming call: teacher cells of the first batch, no student step yet
 
     def step(i, eager=False):
         images, tgt = batches[i % len(batches)]
         if gstep is not None and not eager:
-            ld = gstep(images, tgt)
+            # pipelined: this call runs the teacher on batch i+1 beside the student step on batch i
+            # (one teacher forward and one student step per call either way)
+            ld = gstep(*batches[(i + 1) % len(batches)]) if gstep.pipeline else gstep(images, tgt)
             sched.step()
             return ld
         student._defer_allreduce = False
+        student.net.side_stream = None        # per-launch HIP-event timing wants one kernel at a time
         student.zero_grad()
         with torch.no_grad():
             pred_t = teacher(images, targets=tgt, is_teacher=True)
@@ -201,7 +209,8 @@ def main():
                                       "%s" % (args.student, args.precision, B,
                                               "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
                           "global_batch": B * world, "parallelism": "dp%d" % world,
-                          "launch": "eager" if gstep is None else "hipGraph replay (2 graphs/step)",
+                          "launch": "eager" if gstep is None else ("hipGraph replay (2 graphs/step)" + (
+                              ", teacher(k+1) overlapped with student step(k)" if gstep.pipeline else "")),
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
                "losses_last_step": losses, "finite": finite, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
                "roofline": roof}

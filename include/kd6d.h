@@ -75,11 +75,14 @@ int kd6d_abi_version(void);
  * stats (optional, caller-zeroed): statistics of the stored y accumulated by the epilogue with fp32
  * atomics, so that the normalisation that follows needs no separate reduction pass:
  *   stats_groups == 0: {sum[cout], sumsq[cout]}           (BatchNorm batch statistics, = kd6d_colstats)
- *   stats_groups  > 0: {sum, sumsq} per (level, image, group), the layout kd6d_gn_relu_fwd consumes. */
+ *   stats_groups  > 0: {sum, sumsq} per (level, image, group), the layout kd6d_gn_relu_fwd consumes.
+ * workspace (optional device scratch, any contents): lets layers with few output tiles and a long K run
+ * split-K (fp32 partial slabs + a finalize launch); without it they run as one pass. */
 int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x,
                     const void* w, void* y, const float* ch_scale,
                     const float* ch_shift, int act, const void* residual,
-                    const float* seg_scale, int out_f32, float* stats, int stats_groups, void* stream);
+                    const float* seg_scale, int out_f32, float* stats, int stats_groups,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  wt is the dgrad packing wt[cin][ky][kx][cout]
  * produced by kd6d_pack_dgrad_weights.  accumulate != 0 adds into dx. */

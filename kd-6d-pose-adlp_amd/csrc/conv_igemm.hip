@@ -59,6 +59,8 @@ struct ConvParams {
   int out_f32;
   float* stats;        // optional fused statistics of the stored values (see conv_epilogue_stats)
   int stats_groups;    // 0: per channel {sum[N], sumsq[N]} (BatchNorm); G > 0: {sum, sumsq} per (level, image, group)
+  float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
+  int nk_split;        // k-steps per split
   int stats_cpg_shift; // log2(channels per group): 2 or 3
   float seg_inv_hw[kMaxSeg];   // 1 / (dst_h * dst_w) per level (division-free image index)
 };
@@ -549,7 +551,7 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE>
+template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p) {
   using T = bf16_t;
   constexpr int BK = 64;
@@ -605,8 +607,13 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
     wofs[i] = n < p.N ? n * p.K : -1;
   }
 
+  // split-K: this workgroup contracts k-steps [kt0, kt0 + nk) and leaves an fp32 partial tile
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt0 = SPLIT ? blockIdx.y * p.nk_split : 0;
+  const int nk = SPLIT ? (kt0 + p.nk_split < nk_all ? p.nk_split : nk_all - kt0) : nk_all;
+
   // k-granule decode, advanced incrementally (one wrap per k-step at most when C >= 64)
-  int kk = gk * 8;
+  int kk = kt0 * BK + gk * 8;
   int cc, ky, kx;
   {
     const int tap = kk / p.C;
@@ -669,7 +676,6 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
 #pragma unroll
     for (int q = 0; q < PI; ++q) acc[c][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
   const int fr = lane & 15;
   const int fq = lane >> 4;
 
@@ -710,7 +716,78 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
     }
     if (++stage == NSTAGE) stage = 0;
   }
+  if (SPLIT) {      // raw fp32 partial tile; splitk_finalize_kernel sums the slabs and applies the epilogue
+    float* slab = p.slab + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
+#pragma unroll
+    for (int q = 0; q < PI; ++q) {
+      const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
+        if (n < p.N) *reinterpret_cast<f32x4_t*>(slab + (size_t)m * p.N + n) = acc[c][q];
+      }
+    }
+    return;
+  }
   conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+}
+
+// out = epilogue(sum over splits of the fp32 partial tiles), 4 channels per thread.
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvParams p, int nsplit) {
+  const long long total = (long long)p.M * (p.N >> 2);
+  const size_t stride = (size_t)p.M * (size_t)p.N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (p.N >> 2));
+    const int n = (int)(i - (long long)m * (p.N >> 2)) * 4;
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(p.slab + (size_t)m * p.N + n);
+    for (int s = 1; s < nsplit; ++s) {
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.slab + s * stride + (size_t)m * p.N + n);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    int drow = m, sg = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxSeg; ++q)
+      if (q < p.nseg && m >= p.seg[q].m_begin) { drow = p.seg[q].dst_row0 + (m - p.seg[q].m_begin); sg = q; }
+    const float sscale = p.seg_scale ? p.seg_scale[sg] : 1.f;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.ch_scale) {
+      const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= s4[r];
+    }
+    if (p.ch_shift) {
+      const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += s4[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] *= sscale;
+      if (p.act == KD6D_ACT_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+      else if (p.act == KD6D_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+    }
+    const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
+    if (p.residual) {
+      if (p.out_f32) {
+        const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.residual) + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += r4[r];
+      } else {
+        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rp[r];
+      }
+    }
+    if (p.out_f32) {
+      *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) = f32x4_t{v[0], v[1], v[2], v[3]};
+    } else {
+      u32x2_t pk;
+      pk.x = pack_bf16x2(v[0], v[1]);
+      pk.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1499,6 +1576,59 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   return true;
 }
 
+template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE>
+void launch_splitk(const ConvParams& p, int nsplit, hipStream_t st) {
+  ConvParams q = p;
+  q.n_ctiles = (p.N + BC - 1) / BC;
+  const int ptiles = (p.M + BP - 1) / BP;
+  set_tile_order(q, ptiles, BP, BC);
+  const int nk_all = (p.K + 63) / 64;
+  q.nk_split = (nk_all + nsplit - 1) / nsplit;
+  nsplit = (nk_all + q.nk_split - 1) / q.nk_split;
+  const size_t lds = (size_t)(BP + BC) * 128 * NSTAGE;
+  auto kern = conv_igemm_glds_kernel<BP, BC, WP, WC, MODE, NSTAGE, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles, nsplit), dim3(256), lds, st, q);
+  const long long total = (long long)p.M * (p.N >> 2);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nb), dim3(256), 0, st, q, nsplit);
+}
+
+// Split-K for the layers whose output yields too few tiles to fill 256 CUs while K is long (teacher
+// stages 4/5, FPN top: M <= 4096, K = 2304..9216): partial tiles go to fp32 slabs in the caller's
+// workspace (plain 16-B stores, no atomics), a small second launch sums them and applies the epilogue.
+template <int MODE>
+bool dispatch_splitk(const ConvParams& p, float* ws, size_t ws_bytes, hipStream_t st) {
+  static const int force = []() {
+    const char* e = getenv("KD6D_CONV_SPLITK");   // tuning aid: 0 = off, else tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
+    return e ? atoi(e) : -1;
+  }();
+  if (force == 0 || !ws || p.stats || (p.N & 3) || p.N <= 32) return false;
+  const int nk = (p.K + 63) / 64;
+  auto nblocks = [&](int bp, int bc) { return ((p.M + bp - 1) / bp) * ((p.N + bc - 1) / bc); };
+  int tile = 0, ns = 0;
+  if (force > 0) { tile = force / 100; ns = force % 100; }
+  else if (nk >= 16 && nblocks(64, 64) <= 320) {
+    tile = 2;
+    ns = 768 / nblocks(64, 64);
+    if (ns > nk / 6) ns = nk / 6;
+    if (ns > 16) ns = 16;
+  }
+  if (tile == 0 || ns < 2) return false;
+  if ((size_t)ns * p.M * p.N * sizeof(float) > ws_bytes) return false;
+  ConvParams q = p;
+  q.slab = ws;
+  if (tile == 1) launch_splitk<128, 64, 2, 2, MODE, 3>(q, ns, st);
+  else launch_splitk<64, 64, 2, 2, MODE, 3>(q, ns, st);
+  return true;
+}
+
 // bf16, N > 32: LDS-DMA kernel.  Tile by how many workgroups the layer yields (256 CUs).
 template <int MODE>
 bool dispatch_glds(const ConvParams& p, hipStream_t st) {
@@ -1626,7 +1756,8 @@ void dispatch_wgrad(const WgradParams& p, hipStream_t st) {
 extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
                                void* y, const float* ch_scale, const float* ch_shift, int act,
                                const void* residual, const float* seg_scale, int out_f32,
-                               float* stats, int stats_groups, void* stream) {
+                               float* stats, int stats_groups, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
   int rc = check_geom(g, dtype, "kd6d_conv2d_fwd");
   if (rc) return rc;
   KD6D_CHECK_ARG(x && w && y, "kd6d_conv2d_fwd: null tensor pointer");
@@ -1652,7 +1783,9 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    if (!dispatch_halo<MODE_FWD>(p, g, st) && !dispatch_glds<MODE_FWD>(p, st)) dispatch_igemm<bf16_t, MODE_FWD>(p, st);
+    if (!dispatch_splitk<MODE_FWD>(p, reinterpret_cast<float*>(workspace), (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), st) &&
+        !dispatch_halo<MODE_FWD>(p, g, st) && !dispatch_glds<MODE_FWD>(p, st))
+      dispatch_igemm<bf16_t, MODE_FWD>(p, st);
   } else {
     dispatch_igemm<float, MODE_FWD>(p, st);
   }

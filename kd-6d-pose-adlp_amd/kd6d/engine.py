@@ -176,7 +176,7 @@ class Conv:
             shift = self.bias()
         return ops.conv2d_fwd(g, x, self.weight(), out=out, ch_scale=scale, ch_shift=shift, act=act,
                               residual=residual, seg_scale=seg_scale, out_f32=out_f32, flops=self.flops(g),
-                              stats=stats, stats_groups=stats_groups), g
+                              stats=stats, stats_groups=stats_groups, workspace=self.net.workspace()), g
 
     def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False):
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
@@ -447,6 +447,14 @@ class PoseNet:
         return b
 
     SCRATCH_FLOATS = 1 << 18
+    WORKSPACE_BYTES = 64 << 20      # split-K partial slabs (fp32) of the few-tile / long-K layers
+
+    def workspace(self):
+        ws = self._bufs.get("__workspace__")
+        if ws is None:
+            ws = torch.empty(self.WORKSPACE_BYTES // 4, dtype=torch.float32, device=self.device)
+            self._bufs["__workspace__"] = ws
+        return ws
 
     def scratch(self, name, n):
         """fp32 slice of the per-step scratch arena (zeroed once per step by the training forward)."""

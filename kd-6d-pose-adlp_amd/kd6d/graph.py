@@ -1,11 +1,11 @@
 """hipGraph replay of the whole KD step (train_kd.py:104-140 of the reference).
 
-One step is ~400 kernel launches with static shapes, static buffer addresses and no host
+One step is ~350 kernel launches with static shapes, static buffer addresses and no host
 synchronisation, so launching it from Python costs more host time (~6 ms) than the kernels take.
 `GraphedKDStep` captures it once into two hipGraphs and replays them:
 
-    G1: zero grads -> teacher forward -> teacher cell selection -> student forward -> SSC
-        assignment + focal / object-space / Sinkhorn-OT losses -> backward sweep
+    G1: zero grads -> teacher forward + cell selection  ||  student forward -> SSC assignment +
+        focal / object-space / Sinkhorn-OT losses -> backward sweep (weight gradients on a third stream)
     (eager) RCCL mean all-reduce of the flat gradient bucket, world size > 1 only
     G2: sum of squares -> fused clip + AdamW (+ bf16 shadow refresh)
 
@@ -13,6 +13,13 @@ Everything that changes from step to step enters through device memory: the batc
 static input buffers, the OneCycle learning rate and Adam bias corrections are written by the tiny
 `kd6d_set_hyper` launch (`FusedClipAdamW.advance`), the random keys of the SSC positive sampling
 come from torch's graph-safe Philox generator.
+
+`pipeline=True` additionally software-pipelines ACROSS steps: the frozen teacher does not depend on
+the student's weights, so call k runs the teacher on batch k beside the student's forward/backward
+on batch k-1 (whose teacher cells were produced by call k-1 and are double-buffered).  Every batch
+still gets exactly one teacher forward and one student step; the losses returned by call k belong
+to batch k-1 and `flush()` trains on the last pending batch.  The critical path of a call drops from
+teacher + student to max(teacher, student), and the two halves fill each other's idle CUs.
 """
 import torch
 
@@ -20,31 +27,27 @@ from .kd_losses import DeferredTeacher, PackedTargets
 from .libs import distributed as D
 from .libs.poses import ImageList
 
+
 class GraphedKDStep:
     def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3,
-                 concurrent=True):
+                 concurrent=True, pipeline=False):
         self.teacher, self.student, self.opt = teacher, student, optimizer
         # fork/join inside the captured graph: the teacher's forward runs beside the student's, and the weight
         # gradients beside the dgrad / normalisation chain (many of these kernels fill < 256 CUs on their own)
-        self.teacher_stream = torch.cuda.Stream() if concurrent else None
+        self.teacher_stream = torch.cuda.Stream() if (concurrent or pipeline) else None
         student.net.side_stream = torch.cuda.Stream() if concurrent else None
         self.w_cls, self.w_reg, self.w_kd = (float(w) for w in loss_weights)
         self.cfg_kd = cfg_kd
         self.warmup = warmup
+        self.pipeline = pipeline
         self.g_step = self.g_opt = None
-        self.images = self.tgt = self.losses = None
+        self.images = self.tgt = self.losses = None        # the batch the student trains on
+        self.images_nxt = self.tgt_nxt = None              # pipeline: the batch the teacher looks at
+        self.t_cur = None                                  # pipeline: teacher cells of `images`
+        self.pending = False
 
-    # the body the reference's loop runs per iteration (train_kd.py:104-137)
-    def _forward_backward(self):
-        self.student.zero_grad()
-        with torch.no_grad():
-            if self.teacher_stream is None:
-                pred_t = self.teacher(self.images, targets=self.tgt, is_teacher=True, cfg_kd=self.cfg_kd)
-            else:
-                self.teacher_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.teacher_stream):
-                    pred_t = self.teacher(self.images, targets=self.tgt, is_teacher=True, cfg_kd=self.cfg_kd)
-                pred_t = DeferredTeacher(pred_t, self.teacher_stream)
+    # ---- the body the reference's loop runs per iteration (train_kd.py:104-137) ----------
+    def _student_step(self, pred_t):
         _, ld = self.student(self.images, targets=self.tgt, pred_t=pred_t, cfg_kd=self.cfg_kd)
         loss = ld["loss_cls"] * self.w_cls + ld["loss_reg"] * self.w_reg
         if self.w_kd > 0.0:
@@ -52,20 +55,55 @@ class GraphedKDStep:
         loss.backward()
         return {k: v.detach() for k, v in ld.items()}
 
+    def _teacher(self, images, tgt):
+        with torch.no_grad():
+            if self.teacher_stream is None:
+                return self.teacher(images, targets=tgt, is_teacher=True, cfg_kd=self.cfg_kd)
+            self.teacher_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.teacher_stream):
+                pred = self.teacher(images, targets=tgt, is_teacher=True, cfg_kd=self.cfg_kd)
+            return DeferredTeacher(pred, self.teacher_stream)
+
+    def _forward_backward(self):
+        self.student.zero_grad()
+        if not self.pipeline:
+            return self._student_step(self._teacher(self.images, self.tgt))
+        nxt = self._teacher(self.images_nxt, self.tgt_nxt)       # batch k, beside ...
+        losses = self._student_step(self.t_cur)                  # ... the student step on batch k-1
+        nxt = nxt.join() if isinstance(nxt, DeferredTeacher) else nxt
+        self._advance(nxt)
+        return losses
+
+    def _advance(self, pred_nxt):
+        """k -> k+1: what the teacher just saw becomes the student's next batch."""
+        self.t_cur.copy_from(pred_nxt)
+        self.images.tensors.copy_(self.images_nxt.tensors, non_blocking=True)
+        self.tgt.copy_from(self.tgt_nxt)
+
+    # ---- static inputs ------------------------------------------------------------------------
     def _load(self, images, tgt):
         x = images.tensors if hasattr(images, "tensors") else images
         if self.images is None:
             self.images = ImageList(torch.empty_like(x), getattr(images, "sizes", None))
             self.tgt = tgt.clone_static()
-        assert x.shape == self.images.tensors.shape, "the captured step has a static batch shape"
-        assert (tgt.mask_h, tgt.mask_w) == (self.tgt.mask_h, self.tgt.mask_w)
-        self.images.tensors.copy_(x, non_blocking=True)
-        self.tgt.copy_from(tgt)
+            if self.pipeline:
+                self.images_nxt = ImageList(torch.empty_like(x), getattr(images, "sizes", None))
+                self.tgt_nxt = tgt.clone_static()
+        dst_i, dst_t = (self.images_nxt, self.tgt_nxt) if self.pipeline else (self.images, self.tgt)
+        assert x.shape == dst_i.tensors.shape, "the captured step has a static batch shape"
+        assert (tgt.mask_h, tgt.mask_w) == (dst_t.mask_h, dst_t.mask_w)
+        dst_i.tensors.copy_(x, non_blocking=True)
+        dst_t.copy_from(tgt)
 
+    # ---- capture ------------------------------------------------------------------------------
     def _snapshot(self):
         st, opt = self.student.net.store, self.opt
-        return dict(params=st.params.clone(), bufs=st.bufs.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(),
+        snap = dict(params=st.params.clone(), bufs=st.bufs.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(),
                     nbt=self.student._nbt.clone(), steps=opt.steps, sc=getattr(opt, "_step_count", None))
+        if self.pipeline:
+            snap.update(img=self.images.tensors.clone(), mask=self.tgt.mask.clone(), ff=self.tgt.flat_f.clone(),
+                        fi=self.tgt.flat_i.clone(), tf=self.t_cur.flats[0].clone(), ti=self.t_cur.flats[1].clone())
+        return snap
 
     def _restore(self, snap):
         st, opt = self.student.net.store, self.opt
@@ -77,6 +115,10 @@ class GraphedKDStep:
         opt.steps = snap["steps"]
         if snap["sc"] is not None:
             opt._step_count = snap["sc"]
+        if self.pipeline:                       # the warm-up iterations advanced the pipeline: rewind it
+            self.images.tensors.copy_(snap["img"]); self.tgt.mask.copy_(snap["mask"])
+            self.tgt.flat_f.copy_(snap["ff"]); self.tgt.flat_i.copy_(snap["fi"])
+            self.t_cur.flats[0].copy_(snap["tf"]); self.t_cur.flats[1].copy_(snap["ti"])
 
     def _capture(self):
         self.student._defer_allreduce = True
@@ -112,17 +154,43 @@ class GraphedKDStep:
         if hasattr(self.opt, "_step_count"):
             self.opt._step_count += 1
 
-    def __call__(self, images, tgt):
-        """One KD step on (images, PackedTargets).  Returns the dict of (device, static) loss scalars."""
-        if not isinstance(tgt, PackedTargets):
-            tgt = PackedTargets(tgt, self.student.net.device)
-        first = self.g_step is None
-        self._load(images, tgt)
-        if first:
-            self._capture()
+    def _replay(self):
         self.g_step.replay()
         self._exchange()
         self.opt.advance()
         self.g_opt.replay()
         self._count_opt_step()
         return self.losses
+
+    # ---- public -------------------------------------------------------------------------------
+    def __call__(self, images, tgt):
+        """One KD step.  Returns the dict of (device, static) loss scalars -- of THIS batch, or with
+        pipeline=True of the previous one (None on the priming call)."""
+        if not isinstance(tgt, PackedTargets):
+            tgt = PackedTargets(tgt, self.student.net.device)
+        self._load(images, tgt)
+        if not self.pipeline:
+            if self.g_step is None:
+                self._capture()
+            return self._replay()
+        if self.t_cur is None:                  # priming call: teacher only, the student starts next call
+            with torch.no_grad():
+                pred = self.teacher(self.images_nxt, targets=self.tgt_nxt, is_teacher=True, cfg_kd=self.cfg_kd)
+            self.t_cur = pred.clone_static()
+            self.images.tensors.copy_(self.images_nxt.tensors)
+            self.tgt.copy_from(self.tgt_nxt)
+            self.pending = True
+            return None
+        if self.g_step is None:
+            self._capture()
+        self.pending = True
+        return self._replay()
+
+    def flush(self):
+        """pipeline=True: train on the batch that is still waiting for its student step."""
+        if not (self.pipeline and self.pending and self.t_cur is not None):
+            return None
+        if self.g_step is None:
+            self._capture()
+        self.pending = False
+        return self._replay()      # the teacher re-reads the same (last) batch: harmless, results unused

@@ -110,12 +110,26 @@ class TeacherKnowledge(dict):
     """pred_t of the reference (models/model_kd.py:83-92).  The device-side slot arrays are what the
     student step consumes; the reference-named entries are materialised (with a sync) on demand."""
 
-    def __init__(self, t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta, cap, batch):
+    def __init__(self, t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta, cap, batch, flats=None):
         super().__init__()
         self.t_cnt, self.t_kp, self.t_score, self.t_row = t_cnt, t_kp, t_score, t_row
         self.t_kp_norm, self.t_beta = t_kp_norm, t_beta
         self.cap, self.batch = cap, batch
         self.t_start = torch.arange(batch, dtype=torch.int32, device=t_cnt.device) * cap
+        self.flats = flats            # (fp32, int32) buffers all the slot arrays are views of
+
+    def clone_static(self):
+        """Persistent copy (own storage) that `copy_from` refreshes: the double buffer of the step pipeline."""
+        wf, wi = (t.clone() for t in self.flats)
+        n, b = self.batch * self.cap, self.batch
+        return TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
+                                wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), self.cap, b, (wf, wi))
+
+    def copy_from(self, other):
+        for mine, theirs in zip(self.flats, other.flats):
+            mine.copy_(theirs, non_blocking=True)
+        for key in ("post_kp_2d", "post_kp_cls", "post_pos_per_img"):
+            self.pop(key, None)
 
     def __missing__(self, key):
         if key not in ("post_kp_2d", "post_kp_cls", "post_pos_per_img"):
@@ -154,7 +168,7 @@ def teacher_select(cls_t, reg_t, levels, batch, bbox_trans, th=0.1, positive_num
                                   ops._ptr(t_cnt), ops._ptr(t_kp), ops._ptr(t_score), ops._ptr(t_row),
                                   ops._ptr(t_kp_n), ops._ptr(t_beta), ops._stream()),
           "kd6d_teacher_select")
-    return TeacherKnowledge(t_cnt, t_kp, t_score, t_row, t_kp_n, t_beta, cap, batch)
+    return TeacherKnowledge(t_cnt, t_kp, t_score, t_row, t_kp_n, t_beta, cap, batch, (wf, wi))
 
 
 class KDLoss:

@@ -97,7 +97,7 @@ class Geom:
 
 
 def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE, residual=None,
-               seg_scale=None, out_f32=False, flops=0, stats=None, stats_groups=0):
+               seg_scale=None, out_f32=False, flops=0, stats=None, stats_groups=0, workspace=None):
     assert x.shape == (geom.rows_in, geom.cin), (x.shape, geom.rows_in, geom.cin)
     assert w.dtype == x.dtype and w.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     odt = torch.float32 if out_f32 else x.dtype
@@ -112,7 +112,9 @@ def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE,
     with _Timed("conv_fwd", flops, geom):
         check(lib.kd6d_conv2d_fwd(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(out), _ptr(ch_scale),
                                   _ptr(ch_shift), act, _ptr(residual), _ptr(seg_scale), int(out_f32),
-                                  _ptr(stats), int(stats_groups), _stream()), "kd6d_conv2d_fwd")
+                                  _ptr(stats), int(stats_groups), _ptr(workspace),
+                                  0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                  _stream()), "kd6d_conv2d_fwd")
     return out
 
 

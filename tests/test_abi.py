@@ -31,10 +31,10 @@ def test_argument_checks_fail_loudly_without_gpu():
     g = _lib.ConvGeom()
     g.nseg, g.batch, g.cin, g.cout, g.ksize, g.stride, g.pad = 1, 1, 12, 16, 3, 1, 1   # cin % 8 != 0
     g.seg[0].in_h = g.seg[0].in_w = g.seg[0].out_h = g.seg[0].out_w = 4
-    rc = lib.kd6d_conv2d_fwd(ctypes.byref(g), _lib.KD6D_BF16, None, None, None, None, None, 0, None, None, 0, None, 0, None)
+    rc = lib.kd6d_conv2d_fwd(ctypes.byref(g), _lib.KD6D_BF16, None, None, None, None, None, 0, None, None, 0, None, 0, None, 0, None)
     assert rc == -1 and b"cin=12" in lib.kd6d_last_error()
     g.cin = 16
-    rc = lib.kd6d_conv2d_fwd(ctypes.byref(g), _lib.KD6D_BF16, None, None, None, None, None, 0, None, None, 0, None, 0, None)
+    rc = lib.kd6d_conv2d_fwd(ctypes.byref(g), _lib.KD6D_BF16, None, None, None, None, None, 0, None, None, 0, None, 0, None, 0, None)
     assert rc == -1 and b"null tensor" in lib.kd6d_last_error()
     g.seg[0].out_h = 5
     rc = lib.kd6d_conv2d_dgrad(ctypes.byref(g), _lib.KD6D_F32, None, None, None, 0, None)

@@ -67,6 +67,41 @@ def test_conv_fwd_plain(gpu_device, dtype, case):
         torch.testing.assert_close(gl, ref, **_tol(dtype, stored=False))
 
 
+@pytest.mark.parametrize("case", [
+    # few output tiles, long K: the split-K path (fp32 slabs in the workspace + finalize launch)
+    (2, 256, 128, 3, 1, [(8, 8)]),
+    (1, 512, 200, 3, 2, [(16, 16)]),          # stride 2, N tail (200 = 3 tiles + 8 channels)
+    (2, 1024, 64, 1, 1, [(6, 6), (3, 3)]),    # 1x1, two levels
+])
+def test_conv_fwd_splitk(gpu_device, case):
+    ops = _ops()
+    dtype = torch.bfloat16
+    B, Cin, Cout, k, stride, levels = case
+    g = torch.Generator().manual_seed(5 + Cout)
+    pad = k // 2
+    xs = [round_to(torch.randn(B, Cin, h, w, generator=g), dtype) for (h, w) in levels]
+    w = round_to(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, dtype)
+    geom = ops.Geom(B, Cin, Cout, k, stride, pad, levels)
+    res = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    dev = gpu_device
+    ws = torch.full((8 << 20,), float("nan"), device=dev)          # any contents
+    xp, wp, rp = pack_levels(xs, dtype).to(dev), w_to_krsc(w, dtype).to(dev), pack_levels(res, dtype).to(dev)
+    y_ws = ops.conv2d_fwd(geom, xp, wp, ch_scale=scale.to(dev), ch_shift=shift.to(dev), act=1, residual=rp, workspace=ws)
+    y_1p = ops.conv2d_fwd(geom, xp, wp, ch_scale=scale.to(dev), ch_shift=shift.to(dev), act=1, residual=rp)
+    yf = ops.conv2d_fwd(geom, xp, wp, out_f32=True, workspace=ws)
+    torch.cuda.synchronize()
+    assert not torch.isnan(ws[:geom.rows_out * Cout * 2]).any(), "the split-K path did not run (slabs untouched)"
+    for x, r, a, b_, f in zip(xs, res, unpack_levels(y_ws.cpu(), B, geom.levels_out),
+                              unpack_levels(y_1p.cpu(), B, geom.levels_out), unpack_levels(yf.cpu(), B, geom.levels_out)):
+        conv = F.conv2d(x, w, stride=stride, padding=pad)
+        ref = F.leaky_relu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1) + r
+        torch.testing.assert_close(a, ref, **_tol(dtype, stored=True))
+        torch.testing.assert_close(b_, ref, **_tol(dtype, stored=True))
+        torch.testing.assert_close(f, conv, **_tol(dtype, stored=False))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fwd_epilogue(gpu_device, dtype):
     ops = _ops()

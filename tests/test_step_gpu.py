@@ -253,17 +253,21 @@ def test_graph_replay_matches_eager_steps(gpu_device, precision):
     rows = B * sum((crop // 8 // 2 ** i) ** 2 for i in range(4))
     keys = torch.rand(rows, generator=torch.Generator().manual_seed(3)).to(dev)
 
-    def run(graph):
+    def run(graph, pipeline=False):
         student = build(arch, precision, 1, dev).train()
         student._debug_keys = keys
         opt = FusedClipAdamW(student, lr=1e-3)
         sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 40, pct_start=0.25, cycle_momentum=False,
                                                     anneal_strategy="linear")
-        gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0)) if graph else None
+        gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=pipeline) if graph else None
         hist = []
+        if pipeline:
+            assert gs(*batches[0]) is None            # priming call: teacher only
         for it in range(4):
             img, tgt = batches[it % 2]
-            if gs is not None:
+            if pipeline:                              # call k: teacher on batch k+1, student step on batch k
+                ld = gs(*batches[(it + 1) % 2]) if it < 3 else gs.flush()
+            elif gs is not None:
                 ld = gs(img, tgt)
             else:
                 student.zero_grad()
@@ -286,10 +290,18 @@ def test_graph_replay_matches_eager_steps(gpu_device, precision):
     # the fp32 atomics differs.  Later steps drift apart the way two eager runs do: AdamW's first
     # updates are +-lr * sign(g), which amplifies that noise on near-zero gradients.
     tol = 1e-3 if precision == "fp32" else 2e-2
-    np.testing.assert_allclose(h_g[0], h_e[0], rtol=tol)
+    # the global grad norm sums thousands of atomically accumulated terms: fp32 moves ~1e-3 run to run, bf16 ~2e-2
+    gtol = np.array([tol, tol, tol, 5e-3 if precision == "fp32" else 6e-2])
+    assert (np.abs(h_g[0] - h_e[0]) <= np.abs(h_e[0]) * gtol).all(), (h_g[0], h_e[0])
     np.testing.assert_allclose(h_g[1:, :3], h_e[1:, :3], rtol=0.1)
     d_e, d_g = np.abs(p_e - p0), np.abs(p_g - p0)
     assert d_e.max() > 1e-4, "the eager run did not train"
     # same schedule: the per-parameter travel after 4 steps (~ sum of the 4 learning rates) agrees
     assert abs(d_g.mean() / d_e.mean() - 1.0) < 0.02, (d_g.mean(), d_e.mean())
     assert np.mean(np.abs(p_g - p_e) > 1e-3) < 0.15
+    # cross-step pipeline (teacher of batch k+1 beside the student step of batch k): same training sequence
+    h_p, p_p, n_p = run(True, pipeline=True)
+    assert n_p == 4
+    assert (np.abs(h_p[0] - h_e[0]) <= np.abs(h_e[0]) * gtol).all(), (h_p[0], h_e[0])
+    np.testing.assert_allclose(h_p[1:, :3], h_e[1:, :3], rtol=0.1)
+    assert abs(np.abs(p_p - p0).mean() / d_e.mean() - 1.0) < 0.02

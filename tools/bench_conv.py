@@ -121,6 +121,7 @@ def main():
     print("| layer | kind | M | Cout | K | GFLOP | us | TFLOP/s |")
     print("|---|---|---|---|---|---|---|---|")
     g = torch.Generator(device="cpu").manual_seed(0)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)      # split-K workspace (64 MB)
     for name, cin, cout, k, stride, levels in shapes:
         if a.only and a.only not in name:
             continue
@@ -142,7 +143,7 @@ def main():
                 us = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=yf, out_f32=True, stats=st, stats_groups=a.stats), a.iters)
                 name = name + " (f32 out %.1f us; +stats)" % us0
             elif kind == "fwd":
-                us = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=y), a.iters)
+                us = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=y, workspace=ws), a.iters)
             elif kind == "dgrad":
                 us = timeit(lambda: ops.conv2d_dgrad(geom, dy, w, dx=dx), a.iters)
             else:
