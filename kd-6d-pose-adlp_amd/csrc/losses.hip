@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
     float frame_w, float frame_h, int* __restrict__ t_cnt, float* __restrict__ t_kp,
     float* __restrict__ t_score, int* __restrict__ t_row, float* __restrict__ t_kp_norm,
     float* __restrict__ t_beta) {
+  extern __shared__ float s_cand[];     // cells of the largest level
   __shared__ float s_v[kT / 64];
   __shared__ int s_i[kT / 64];
   __shared__ unsigned s_mask;
@@ -146,20 +147,22 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
       level_fields(L, l, h, w, row0, st, sz);
       const int hw = h * w;
       const int want = s_nk[l];
-      float last_v = INFINITY; int last_i = -1;
+      if (want <= 0) continue;
+      // candidate scores of this (class, level) once into LDS; every pick then scans LDS and is struck out
+      for (int cell = threadIdx.x; cell < hw; cell += kT) {
+        const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
+        s_cand[cell] = p > th ? sqrtf(p) : -1.f;
+      }
+      __syncthreads();
       for (int t = 0; t < want; ++t) {
         float bv = -1.f; int bi = 0x7fffffff;
         for (int cell = threadIdx.x; cell < hw; cell += kT) {
-          const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
-          if (p > th) {
-            const float s = sqrtf(p);
-            const bool after = (s < last_v) || (s == last_v && cell > last_i);
-            if (after && (s > bv || (s == bv && cell < bi))) { bv = s; bi = cell; }
-          }
+          const float sc = s_cand[cell];
+          if (sc > bv) { bv = sc; bi = cell; }      // ascending cells per thread: ties keep the smaller index
         }
         block_argmax(bv, bi, s_v, s_i);
         if (bv <= 0.f) break;          // fewer candidates than n_l
-        last_v = bv; last_i = bi;
+        if (threadIdx.x == 0) s_cand[bi] = -1.f;
         const int slot = s_total;      // uniform: written only after the barrier below
         if (slot < cap && threadIdx.x < 8) {
           const int k = threadIdx.x;
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
     const float* __restrict__ bbox_trans, const float* __restrict__ keys, float positive_num,
     float positive_lambda, int cap, int* __restrict__ labels, int* __restrict__ pos_cnt,
     int* __restrict__ pos_row, int* __restrict__ pos_gt) {
+  extern __shared__ float s_cand[];     // cells of the largest level
   __shared__ float s_v[kT / 64];
   __shared__ int s_i[kT / 64];
   __shared__ int s_has[kMaxGt];
@@ -219,7 +223,16 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
   // which instances are present in the mask (poses.py:269-278)
   {
     int has[kMaxGt] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < mh * mw; i += kT) {
+    const int n4 = ((mh * mw) & 3) == 0 && ((reinterpret_cast<uintptr_t>(m) & 15) == 0) ? (mh * mw) >> 2 : 0;
+    const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(m);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += kT) {
+      const f32x4_t v = m4[i];
+#pragma unroll
+      for (int g = 0; g < kMaxGt; ++g)
+        has[g] |= (v[0] == (float)(g + 1)) | (v[1] == (float)(g + 1)) | (v[2] == (float)(g + 1)) | (v[3] == (float)(g + 1));
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < mh * mw; i += kT) {
       const float v = m[i];
 #pragma unroll
       for (int g = 0; g < kMaxGt; ++g) has[g] |= (v == (float)(g + 1));
@@ -288,26 +301,28 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
         if (q == l) wl = e;
       }
       const int want = (int)(positive_num * wl / sum + 0.5f);
-      float last_v = INFINITY; int last_i = -1;   // keys are negated so arg-max picks the smallest key
+      if (want <= 0) continue;
+      // negated keys of the in-mask cells of this (level, instance) once into LDS (arg-max = smallest key)
+      for (int cell = threadIdx.x; cell < hw; cell += kT) {
+        const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
+        const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
+        const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
+        s_cand[cell] = (m[iy * mw + ix] == (float)(g + 1)) ? -keys[row0 + b * hw + cell] : -INFINITY;
+      }
+      __syncthreads();
       for (int t = 0; t < want; ++t) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int cell = threadIdx.x; cell < hw; cell += kT) {
-          const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
-          const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
-          const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
-          if (m[iy * mw + ix] == (float)(g + 1)) {
-            const float s = -keys[row0 + b * hw + cell];
-            const bool after = (s < last_v) || (s == last_v && cell > last_i);
-            if (after && (s > bv || (s == bv && cell < bi))) { bv = s; bi = cell; }
-          }
+          const float sc = s_cand[cell];
+          if (sc > bv) { bv = sc; bi = cell; }
         }
         block_argmax(bv, bi, s_v, s_i);
         if (bi == 0x7fffffff) break;   // fewer in-mask cells than n_k
-        last_v = bv; last_i = bi;
         if (threadIdx.x == 0) {
           const int slot = s_total;
           if (slot < 64) { s_sel_row[slot] = row0 + b * hw + bi; s_sel_gt[slot] = g; }
           s_total = slot + 1;
+          s_cand[bi] = -INFINITY;
         }
         __syncthreads();
       }
@@ -576,6 +591,15 @@ bool fill_levels(const kd6d_levels* lv, Levels* L) {
 
 }  // namespace
 
+static size_t max_level_cells(const Levels& L) {
+  size_t m = 1;
+  for (int l = 0; l < L.n; ++l) {
+    const size_t c = (size_t)L.h[l] * (size_t)L.w[l];
+    if (c > m) m = c;
+  }
+  return m;
+}
+
 extern "C" int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, const float* reg,
                                    const float* bbox_trans, float threshold, float positive_num,
                                    float positive_lambda, int cap, float frame_w, float frame_h,
@@ -587,7 +611,8 @@ extern "C" int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, 
                      frame_w > 0.f && frame_h > 0.f,
                  "kd6d_teacher_select: bad arguments");
   KD6D_CHECK_ARG(threshold > 0.f && threshold < 1.f, "kd6d_teacher_select: threshold must be in (0,1)");
-  hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch), dim3(kT), max_level_cells(L) * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream),
                      cls, reg, L, bbox_trans, threshold, positive_num, positive_lambda, cap, frame_w, frame_h,
                      t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta);
   KD6D_CHECK_LAUNCH("kd6d_teacher_select");
@@ -605,7 +630,8 @@ extern "C" int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int
   KD6D_CHECK_ARG(mask && kp3d && K && class_ids && n_gt && rot && trans && bbox_trans && keys && labels &&
                      pos_cnt && pos_row && pos_gt && cap > 0 && cap <= 64 && mask_h > 0 && mask_w > 0,
                  "kd6d_ssc_assign: bad arguments (cap must be in 1..64)");
-  hipLaunchKernelGGL(ssc_assign_kernel, dim3(L.batch), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), L,
+  hipLaunchKernelGGL(ssc_assign_kernel, dim3(L.batch), dim3(kT), max_level_cells(L) * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), L,
                      mask, mask_h, mask_w, kp3d, K, class_ids, n_gt, rot, trans, bbox_trans, keys,
                      positive_num, positive_lambda, cap, labels, pos_cnt, pos_row, pos_gt);
   KD6D_CHECK_LAUNCH("kd6d_ssc_assign");

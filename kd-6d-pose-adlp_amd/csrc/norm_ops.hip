@@ -414,13 +414,45 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
       a_dyx[e] += d * xh;
     }
   }
+  // lanes l, l + cgs, l + 2 cgs ... of a wave own the same channel granule (cgs = 16 or 32 here): fold them
+  // with shuffles first -- 16- to 64-way same-address LDS float atomics serialise and were the whole cost
+  const bool fold = (cgs == 16 || cgs == 32);
+  if (fold) {
 #pragma unroll
-  for (int e = 0; e < EG; ++e) {
-    const int c = cg * EG + e;
-    atomicAdd(&red[c], a_dy[e]);
-    atomicAdd(&red[C + c], a_dyx[e]);
-    atomicAdd(&s_a[c / cpg], a_dy[e] * ga[e]);
-    atomicAdd(&s_b[c / cpg], a_dyx[e] * ga[e]);
+    for (int e = 0; e < EG; ++e) {
+      a_dy[e] += __shfl_xor(a_dy[e], 32, 64);
+      a_dyx[e] += __shfl_xor(a_dyx[e], 32, 64);
+      if (cgs == 16) {
+        a_dy[e] += __shfl_xor(a_dy[e], 16, 64);
+        a_dyx[e] += __shfl_xor(a_dyx[e], 16, 64);
+      }
+    }
+  }
+  if (!fold || (int)(threadIdx.x & 63) < cgs) {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int c = cg * EG + e;
+      atomicAdd(&red[c], a_dy[e]);
+      atomicAdd(&red[C + c], a_dyx[e]);
+    }
+    // group sums: add up the lane's channels of one group in registers first
+#pragma unroll
+    for (int e0 = 0; e0 < EG; e0 += 4) {        // cpg is 4 or a multiple of 4 here -> 4 aligned channels share a group
+      const int c = cg * EG + e0;
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int e = e0; e < e0 + 4; ++e) { sa += a_dy[e] * ga[e]; sb += a_dyx[e] * ga[e]; }
+      if ((cpg & 3) == 0) {
+        atomicAdd(&s_a[c / cpg], sa);
+        atomicAdd(&s_b[c / cpg], sb);
+      } else {
+#pragma unroll
+        for (int e = e0; e < e0 + 4; ++e) {
+          atomicAdd(&s_a[(cg * EG + e) / cpg], a_dy[e] * ga[e]);
+          atomicAdd(&s_b[(cg * EG + e) / cpg], a_dyx[e] * ga[e]);
+        }
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x < G) {
@@ -722,7 +754,7 @@ extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, floa
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int rpp = kThreads / (C / eg);
   long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
-  if (nb > 1024) nb = 1024;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
   DISPATCH_T(dtype,
@@ -774,8 +806,10 @@ extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   const long long ngran = rows * (C / eg);
+  // every workgroup ends with one global atomic per channel and same-address atomics retire serially
+  // (~25 ns each): 2 workgroups per CU keep the loads in flight without a 1000-deep atomic queue
   long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
-  if (nb > 1024) nb = 1024;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
   DISPATCH_TTX(dtype, x_f32,

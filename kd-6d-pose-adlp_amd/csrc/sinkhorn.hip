@@ -31,24 +31,46 @@ struct WaveLds {
   float hy1[kCap], hy2[kCap];           // lb + b_y/eps, lb + a_y/eps
 };
 
-// logsumexp_j( h_j - 0.5*|r - c_j|^2 * inv_eps ); optionally softmax-weighted sum of (r - c_j)
+// logsumexp_j( h_j - 0.5*|r - c_j|^2 * inv_eps ); optionally softmax-weighted sum of (r - c_j).
+// One pass (running max with rescaling) over 4 columns at a time: the three 16-byte LDS broadcasts of a
+// chunk are issued together, so the ~100-cycle LDS latency is paid once per 4 columns instead of 3x per
+// column -- this loop is a pure dependency chain and was the whole cost of the kernel.
 template <bool GRAD>
 __device__ __forceinline__ float lse_row(float rx, float ry, const float* cx, const float* cy,
                                          const float* h, int n, float inv_eps, float& gx,
                                          float& gy) {
-  float m = -INFINITY;
-  for (int j = 0; j < n; ++j) {
-    const float dx = rx - cx[j], dy = ry - cy[j];
-    const float v = h[j] - 0.5f * (dx * dx + dy * dy) * inv_eps;
-    m = fmaxf(m, v);
+  float m = -INFINITY, s = 0.f, sx = 0.f, sy = 0.f;
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    const f32x4_t X = *reinterpret_cast<const f32x4_t*>(cx + j);
+    const f32x4_t Y = *reinterpret_cast<const f32x4_t*>(cy + j);
+    const f32x4_t H = *reinterpret_cast<const f32x4_t*>(h + j);
+    float dx[4], dy[4], v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      dx[t] = rx - X[t]; dy[t] = ry - Y[t];
+      v[t] = H[t] - 0.5f * (dx[t] * dx[t] + dy[t] * dy[t]) * inv_eps;
+    }
+    const float mn = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    const float sc = expf(m - mn);            // 0 on the first chunk (m = -inf), 1 when the max did not move
+    s *= sc;
+    if (GRAD) { sx *= sc; sy *= sc; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float e = expf(v[t] - mn);
+      s += e;
+      if (GRAD) { sx += e * dx[t]; sy += e * dy[t]; }
+    }
+    m = mn;
   }
-  float s = 0.f, sx = 0.f, sy = 0.f;
-  for (int j = 0; j < n; ++j) {
+  for (; j < n; ++j) {
     const float dx = rx - cx[j], dy = ry - cy[j];
     const float v = h[j] - 0.5f * (dx * dx + dy * dy) * inv_eps;
-    const float e = expf(v - m);
-    s += e;
-    if (GRAD) { sx += e * dx; sy += e * dy; }
+    const float mn = fmaxf(m, v);
+    const float sc = expf(m - mn), e = expf(v - mn);
+    s = s * sc + e;
+    if (GRAD) { sx = sx * sc + e * dx; sy = sy * sc + e * dy; }
+    m = mn;
   }
   if (GRAD) { gx = sx / s; gy = sy / s; }
   return m + logf(s);
@@ -127,6 +149,16 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
     if (idx <= n_ar) return exp(e_start + (double)(idx - 1) * e_step);
     return (double)blur * (double)blur;
   };
+  // the fp64 schedule once per workgroup (lane i evaluates step i) instead of once per thread and step
+  constexpr int kSched = 128;
+  __shared__ float s_feps[kSched], s_inv[kSched], s_lam[kSched];
+  for (int i = threadIdx.x; i < n_eps && i < kSched; i += blockDim.x) {
+    const double e = eps_at(i);
+    s_feps[i] = (float)e;
+    s_inv[i] = (float)(1.0 / e);
+    s_lam[i] = unbalanced ? (float)(1.0 / (1.0 + e / rho)) : 1.f;
+  }
+  __syncthreads();
 
   // ---- initialisation at eps_0 -------------------------------------------------
   {
@@ -148,11 +180,15 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
   __syncthreads();
 
   // ---- epsilon-scaling loop (no gradient) ----------------------------------------
-  double eps = eps_at(0);
   for (int it = 0; it < n_eps; ++it) {
-    eps = eps_at(it);
-    const float lam = unbalanced ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
-    const float feps = (float)eps, inv = (float)(1.0 / eps);
+    float lam, feps, inv;
+    if (it < kSched) {
+      lam = s_lam[it]; feps = s_feps[it]; inv = s_inv[it];
+    } else {
+      const double e = eps_at(it);
+      lam = unbalanced ? (float)(1.0 / (1.0 + e / rho)) : 1.f;
+      feps = (float)e; inv = (float)(1.0 / e);
+    }
     for (int i = lane; i < N; i += 64) {
       L.hx1[i] = L.la[i] + L.ax[i] * inv;
       L.hx2[i] = L.la[i] + L.bx[i] * inv;
@@ -181,6 +217,7 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
   }
 
   // ---- last extrapolation (carries the gradient) + debiased cost -------------------
+  const double eps = eps_at(n_eps - 1);
   const float lam = unbalanced ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
   const float feps = (float)eps, inv = (float)(1.0 / eps);
   for (int i = lane; i < N; i += 64) {

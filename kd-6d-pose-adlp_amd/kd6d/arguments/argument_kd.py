@@ -56,6 +56,9 @@ def get_argparser():
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--synthetic", action="store_true", help="seeded LINEMOD-shaped synthetic batches (no dataset)")
     p.add_argument("--skip_teacher_eval", action="store_true")
+    p.add_argument("--launch", type=str, default="graph", choices=["graph", "pipeline", "eager"],
+                   help="graph: replay the captured step (hipGraph); pipeline: also overlap the teacher forward of "
+                        "the next batch with the student step of the current one; eager: launch kernel by kernel")
     p.add_argument("--batch_size", type=int, default=0, help="global batch; 0 = SOLVER.IMS_PER_BATCH")
     p.add_argument("--image_size", type=int, default=256, help="synthetic crop size")
     return p
@@ -73,6 +76,7 @@ def build_cfgs(args):
     cfg["RUNTIME"]["WORKING_DIR"] = args.working_dir
     cfg["RUNTIME"]["SYNTHETIC"] = bool(args.synthetic)
     cfg["RUNTIME"]["SKIP_TEACHER_EVAL"] = bool(args.skip_teacher_eval)
+    cfg["RUNTIME"]["LAUNCH"] = args.launch
     cfg["RUNTIME"]["IMAGE_SIZE"] = int(args.image_size)
     if len(args.test_file) > 0:
         cfg["DATASETS"]["TEST"] = args.test_file

@@ -87,25 +87,42 @@ if __name__ == "__main__":
     cfg_kd = cfg["KD"]
     w_cls, w_reg, w_kd = cfg["SOLVER"]["LOSS_WEIGHT_CLS"], cfg["SOLVER"]["LOSS_WEIGHT_REG"], cfg["KD"]["LOSS_WEIGHT_KD"]
     t0 = time.time()
+    launch = cfg["RUNTIME"].get("LAUNCH", "graph")
+    gstep = None
+    if launch != "eager":
+        from kd6d.graph import GraphedKDStep
+        gstep = GraphedKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd,
+                              pipeline=(launch == "pipeline"))
     for idx, (images, targets, _) in enumerate(train_loader):
         if total_steps >= cfg["SOLVER"]["MAX_ITER"]:
+            if gstep is not None:
+                gstep.flush()      # pipeline mode: the last batch still waits for its student step
             if get_rank() == 0:
                 torch.save(model.state_dict(), os.path.join(wd, "final.pth"))
             print("Training finished")
             break
-        total_steps += 1
-        model.zero_grad()
-        with torch.no_grad():
-            pred_t = model_t(images, targets=targets, is_teacher=True, cfg_kd=cfg_kd)
-        _, loss_dict = model(images, targets=targets, pred_t=pred_t, cfg_kd=cfg_kd)
-        loss_cls = (loss_dict["loss_cls"] * w_cls).mean()
-        loss_reg = (loss_dict["loss_reg"] * w_reg).mean()
-        loss = loss_cls + loss_reg
-        loss_kd = (loss_dict["loss_kd"] * w_kd).mean()
-        if w_kd > 0.0:
-            loss = loss + loss_kd
-        loss.backward()
-        optimizer.step()          # clip_grad_norm_(GRAD_CLIP) is fused into the optimiser kernel
+        if gstep is not None:
+            # the same iteration body (train_kd.py:104-140 of the reference), captured once and replayed
+            loss_dict = gstep(images, targets)
+            if loss_dict is None:          # priming call of the pipeline: teacher only
+                continue
+            total_steps += 1
+            loss_cls, loss_reg, loss_kd = (loss_dict["loss_cls"] * w_cls, loss_dict["loss_reg"] * w_reg,
+                                           loss_dict["loss_kd"] * w_kd)
+        else:
+            total_steps += 1
+            model.zero_grad()
+            with torch.no_grad():
+                pred_t = model_t(images, targets=targets, is_teacher=True, cfg_kd=cfg_kd)
+            _, loss_dict = model(images, targets=targets, pred_t=pred_t, cfg_kd=cfg_kd)
+            loss_cls = (loss_dict["loss_cls"] * w_cls).mean()
+            loss_reg = (loss_dict["loss_reg"] * w_reg).mean()
+            loss = loss_cls + loss_reg
+            loss_kd = (loss_dict["loss_kd"] * w_kd).mean()
+            if w_kd > 0.0:
+                loss = loss + loss_kd
+            loss.backward()
+            optimizer.step()          # clip_grad_norm_(GRAD_CLIP) is fused into the optimiser kernel
         scheduler.step()
         if get_rank() == 0 and (total_steps % 50 == 0 or total_steps == 1):
             dt = time.time() - t0
