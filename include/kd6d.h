@@ -224,6 +224,22 @@ int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const float* cls, c
                        float* dseg_scale, float frame_w, float frame_h, int cap, int detach_alpha, void* dcls,
                        void* dreg, void* stream);
 
+/* ---- dense optimal transport (BASELINE config 5: D-dimensional local predictions over a whole cell grid,
+ * thousands of points per set; the reference would need geomloss' KeOps backend above 5000^2 pairs).  Same
+ * divergence and gradients as kd6d_sinkhorn_div_fwd_bwd for ONE problem: x (N,D) with weights alpha (N)
+ * against y (M,D) with beta (M), D in {2,4,8,16}; cost matrices are never materialised (online logsumexp over
+ * LDS-staged column tiles).  `diameter` > 0 is the box diagonal of all points (geomloss' diameter= argument);
+ * kd6d_sinkhorn_dense_diameter computes it on the device (scratch64: 64 floats).  workspace:
+ * kd6d_sinkhorn_dense_workspace_floats(N, M, D) floats, any contents.  Outputs: loss (1), grad_x (N,D),
+ * grad_alpha (N). */
+int64_t kd6d_sinkhorn_dense_workspace_floats(int N, int M, int D);
+int kd6d_sinkhorn_dense_diameter(const float* x, const float* y, int N, int M, int D, float* scratch64,
+                                 float* diam_out, void* stream);
+int kd6d_sinkhorn_dense_fwd_bwd(const float* x, const float* alpha, const float* y, const float* beta, int N, int M,
+                                int D, float p, float blur, float scaling, float reach, double diameter,
+                                float* workspace, int64_t workspace_floats, float* loss, float* grad_x,
+                                float* grad_alpha, void* stream);
+
 /* ---- optimiser: replaces clip_grad_norm_ + AdamW.step of train_kd.py:138-139 on one flat buffer.
  * kd6d_sumsq accumulates sum(x^2) into *out (pre-zeroed); kd6d_clip_adamw applies
  * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update

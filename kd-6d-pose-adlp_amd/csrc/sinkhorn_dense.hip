@@ -1,0 +1,379 @@
+// Dense Sinkhorn divergence: thousands of points per set, D-dimensional local predictions
+// (BASELINE config 5: ZebraPose-style 16-D code predictions over a 128x128 cell grid,
+// N = M = 16384).  Same algorithm as sinkhorn.hip / SURVEY.md App. B -- geomloss 0.2.4
+// SamplesLoss("sinkhorn", p=2, debias=True, reach) with epsilon scaling, symmetrised updates and a
+// detached last extrapolation that carries the gradient -- but the N x M cost matrices (4 x 1 GiB at
+// this size) are NEVER materialised: every softmin is an online logsumexp over column tiles staged
+// in LDS ("flash" form), so a pass streams (N+M)(D+2) floats from HBM and is bound by the fp32 VALU
+// + v_exp_f32 rate (~40 lane-ops per pair), not by memory.  The reference itself cannot run this
+// size: geomloss switches to the KeOps backend above 5000^2 pairs and pykeops is not among its
+// requirements.
+//
+// Cost is evaluated from coordinate DIFFERENCES, 0.5*|r - c|^2, not from the |r|^2 - 2 r.c + |c|^2
+// expansion: at blur = 1e-3 (eps = 1e-6) the expansion cancels catastrophically in fp32 for exactly
+// the near pairs that dominate the softmin, so a matrix-core dot product would be fast and wrong.
+//
+// One launch = the four softmins of one epsilon step (blockIdx.y selects x<-x, y<-y, y<-x, x<-y);
+// thread = one row with its D coordinates in registers; 4 columns per inner step; exponentials in the
+// exp2 domain (v_exp_f32).  Potentials are double-buffered so all four updates read the old values.
+#include <math.h>
+
+#include "kd6d_common.h"
+
+namespace {
+
+constexpr int kRows = 256;        // rows per workgroup
+constexpr int kSplit = 2;         // threads per row: each takes every kSplit-th half of a column tile, merged at the end
+constexpr int kThreadsD = kRows * kSplit;   // 512 threads = 2 waves per SIMD: a lone wave issues one VALU op per 4+ clk
+constexpr int kTile = 128;        // columns staged per LDS tile (kTile / kSplit per thread)
+constexpr float kNegLogD = -100000.f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct DenseArgs {
+  const float* x; const float* y;          // (N,D), (M,D)
+  const float* la; const float* lb;        // log weights (N), (M)
+  const float* pot_old;                    // [a_x (N) | b_x (N) | b_y (M) | a_y (M)]
+  float* pot_new;
+  int N, M;
+  int mode;                                // 0: init (h = log w), 1: symmetrised update, 2: last extrapolation
+  float eps, lam;                          // epsilon, 1/(1+eps/rho) (1 if balanced)
+  float* grad_xx; float* grad_xy;          // mode 2: softmax-weighted sums of (x_i - c_j), (N,D) each
+};
+
+// potentials layout helpers
+__device__ __forceinline__ int off_ax(const DenseArgs&) { return 0; }
+__device__ __forceinline__ int off_bx(const DenseArgs& a) { return a.N; }
+__device__ __forceinline__ int off_by(const DenseArgs& a) { return 2 * a.N; }
+__device__ __forceinline__ int off_ay(const DenseArgs& a) { return 2 * a.N + a.M; }
+
+template <int D, bool GRAD>
+__global__ __launch_bounds__(kThreadsD) void dense_softmin_kernel(const DenseArgs a) {
+  constexpr int P = (D + 4) & ~3;          // LDS pitch: D coords + h (+ pad), a multiple of 16 bytes
+  __shared__ __attribute__((aligned(16))) float tile[2][kTile * P];
+  __shared__ float mrg[kRows * (GRAD ? D + 2 : 2)];     // partial (m, s, g) of the second column half
+
+  // which of the four softmins: rows / columns / column potential / output slot
+  const int which = blockIdx.y;            // 0: a_x (x<-x)  1: b_y (y<-y)  2: a_y (y<-x)  3: b_x (x<-y)
+  const bool rows_x = (which == 0 || which == 3);
+  const bool cols_x = (which == 0 || which == 2);
+  const float* R = rows_x ? a.x : a.y;
+  const float* Cc = cols_x ? a.x : a.y;
+  const int nr = rows_x ? a.N : a.M;
+  const int nc = cols_x ? a.N : a.M;
+  const float* lw = cols_x ? a.la : a.lb;
+  // column potential of the update (App. B): a_x uses a_x, b_y uses b_y, a_y uses b_x, b_x uses a_y
+  const int cpot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_bx(a) : off_ay(a);
+  const int opot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_ay(a) : off_bx(a);
+
+  const int lrow = threadIdx.x % kRows;
+  const int part = threadIdx.x / kRows;    // which share of every column tile this thread reduces
+  const int row = blockIdx.x * kRows + lrow;
+  if (blockIdx.x * kRows >= nr) return;    // uniform per workgroup
+  const bool rok = row < nr;
+  float r[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) r[d] = rok ? R[(size_t)row * D + d] : 0.f;
+
+  const float inv_eps = 1.f / a.eps;
+  const float k2 = 0.5f * inv_eps * kLog2e;      // exp2-domain scale of the squared distance
+  float m = -INFINITY, s = 0.f;
+  float g[GRAD ? D : 1];
+#pragma unroll
+  for (int d = 0; d < (GRAD ? D : 1); ++d) g[d] = 0.f;
+
+  auto stage = [&](int buf, int c0) {
+    // kTile columns x (D coords + h): one float per thread-iteration, coalesced on the coordinate array
+    for (int i = threadIdx.x; i < kTile * D; i += kThreadsD) {
+      const int c = i / D, d = i - c * D;
+      tile[buf][c * P + d] = (c0 + c < nc) ? Cc[(size_t)(c0 + c) * D + d] : 0.f;
+    }
+    for (int c = threadIdx.x; c < kTile; c += kThreadsD) {
+      float h = -INFINITY;                 // padding columns never contribute
+      if (c0 + c < nc) {
+        h = lw[c0 + c];
+        if (a.mode != 0) h += a.pot_old[cpot + c0 + c] * inv_eps;
+        h *= kLog2e;
+      }
+      tile[buf][c * P + D] = h;
+    }
+  };
+
+  const int ntiles = (nc + kTile - 1) / kTile;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * kTile);
+    const float* T = tile[buf] + part * (kTile / kSplit) * P;
+#pragma unroll 1
+    for (int c = 0; c < kTile / kSplit; c += 4) {
+      float v[4], dd[4][GRAD ? D : 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* col = T + (c + u) * P;
+        float d2 = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < D; d4 += 4) {
+          const f32x4_t cv = *reinterpret_cast<const f32x4_t*>(col + d4);     // LDS broadcast
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (d4 + e < D) {
+              const float df = r[d4 + e] - cv[e];
+              d2 += df * df;
+              if (GRAD) dd[u][d4 + e] = df;
+            }
+          }
+        }
+        v[u] = col[D] - d2 * k2;
+      }
+      const float mn = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+      if (mn > -INFINITY) {
+        const float sc = __builtin_amdgcn_exp2f(m - mn);
+        s *= sc;
+        if (GRAD) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) g[d] *= sc;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float e = __builtin_amdgcn_exp2f(v[u] - mn);
+          s += e;
+          if (GRAD) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) g[d] += e * dd[u][d];
+          }
+        }
+        m = mn;
+      }
+    }
+    __syncthreads();
+  }
+  // merge the column shares of a row: logsumexp of two partial (max, sum) pairs
+  if (part == 1) {
+    mrg[lrow * (GRAD ? D + 2 : 2) + 0] = m;
+    mrg[lrow * (GRAD ? D + 2 : 2) + 1] = s;
+    if (GRAD) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) mrg[lrow * (D + 2) + 2 + d] = g[d];
+    }
+  }
+  __syncthreads();
+  if (part != 0 || !rok) return;
+  {
+    const float m2 = mrg[lrow * (GRAD ? D + 2 : 2) + 0], s2 = mrg[lrow * (GRAD ? D + 2 : 2) + 1];
+    const float mn = fmaxf(m, m2);
+    const float c1 = m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f;
+    const float c2 = m2 > -INFINITY ? __builtin_amdgcn_exp2f(m2 - mn) : 0.f;
+    s = s * c1 + s2 * c2;
+    if (GRAD) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) g[d] = g[d] * c1 + mrg[lrow * (D + 2) + 2 + d] * c2;
+    }
+    m = mn;
+  }
+  // softmin = -eps * logsumexp;  back from the exp2 domain
+  const float lse = (m + __builtin_amdgcn_logf(s)) * kLn2;     // v_log_f32 = log2
+  const float val = -a.lam * a.eps * lse;
+  if (a.mode == 1) a.pot_new[opot + row] = 0.5f * (a.pot_old[opot + row] + val);
+  else a.pot_new[opot + row] = val;
+  if (GRAD && (which == 0 || which == 3)) {
+    float* go = (which == 0 ? a.grad_xx : a.grad_xy) + (size_t)row * D;
+    const float inv_s = 1.f / s;
+#pragma unroll
+    for (int d = 0; d < D; ++d) go[d] = g[d] * inv_s;
+  }
+}
+
+// log weights (with geomloss' -1e5 for non-positive weights)
+__global__ void dense_logw_kernel(const float* __restrict__ w, float* __restrict__ lw, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) lw[i] = w[i] > 0.f ? logf(w[i]) : kNegLogD;
+}
+
+// debiased cost, dS/dalpha and dS/dx from the final potentials (App. B "value" block + autograd rules)
+template <int D>
+__global__ __launch_bounds__(256) void dense_finalize_kernel(
+    const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ pot, int N, int M,
+    float eps, float lam, float rho, const float* __restrict__ grad_xx, const float* __restrict__ grad_xy,
+    float* __restrict__ loss, float* __restrict__ gx_out, float* __restrict__ galpha_out) {
+  __shared__ float s_part[4];
+  const bool unb = rho > 0.f;
+  const float w_unb = rho + 0.5f * eps, inv_rho = unb ? 1.f / rho : 0.f;
+  const float* ax = pot; const float* bx = pot + N; const float* by = pot + 2 * N; const float* ay = pot + 2 * N + M;
+  float part = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const float a = alpha[i];
+    float dS;
+    float cxx, cxy;          // coefficients of the two softmax-weighted difference sums
+    if (unb) {
+      const float ea = expf(-ax[i] * inv_rho), eb = expf(-bx[i] * inv_rho);
+      dS = w_unb * (ea - eb);
+      const float c = -a * w_unb * inv_rho * lam;
+      cxx = c * ea; cxy = -c * eb;
+    } else {
+      dS = bx[i] - ax[i];
+      cxx = -a; cxy = a;
+    }
+    part += a * dS;
+    galpha_out[i] = dS;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      gx_out[(size_t)i * D + d] = cxx * grad_xx[(size_t)i * D + d] + cxy * grad_xy[(size_t)i * D + d];
+  }
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < M; j += gridDim.x * 256) {
+    const float w = beta[j];
+    if (unb) part += w * w_unb * (expf(-by[j] * inv_rho) - expf(-ay[j] * inv_rho));
+    else part += w * (ay[j] - by[j]);
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// coordinate-wise min / max over all points of both sets -> box diagonal (geomloss max_diameter)
+__global__ __launch_bounds__(256) void dense_minmax_kernel(const float* __restrict__ p, long long n, int D,
+                                                           float* __restrict__ mn, float* __restrict__ mx) {
+  // thread t owns coordinate t % D (256 % D == 0 for D in {2,4,8,16})
+  const int d = threadIdx.x % D;
+  float lo = INFINITY, hi = -INFINITY;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n * D; i += (long long)gridDim.x * 256) {
+    const float v = p[i];
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  // float atomics on the bit pattern need sign care; all reductions here go through int CAS-free min/max of
+  // ordered ints: map float -> monotone int
+  auto ord = [](float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; };
+  atomicMin(reinterpret_cast<int*>(mn) + d, ord(lo));
+  atomicMax(reinterpret_cast<int*>(mx) + d, ord(hi));
+}
+
+__global__ void dense_diam_kernel(const float* mn, const float* mx, int D, float* diam) {
+  if (threadIdx.x == 0) {
+    auto unord = [](int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); };
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float e = unord(reinterpret_cast<const int*>(mx)[d]) - unord(reinterpret_cast<const int*>(mn)[d]);
+      s += e * e;
+    }
+    diam[0] = sqrtf(s);
+  }
+}
+
+template <int D>
+int run_dense(const float* x, const float* alpha, const float* y, const float* beta, int N, int M, float blur,
+              float scaling, float reach, double diameter, float* ws, float* loss, float* gx, float* galpha,
+              hipStream_t st) {
+  // workspace: la (N) | lb (M) | pot A (2N+2M) | pot B (2N+2M) | grad_xx (N*D) | grad_xy (N*D)
+  float* la = ws;
+  float* lb = la + N;
+  float* potA = lb + M;
+  float* potB = potA + 2 * (size_t)(N + M);
+  float* gxx = potB + 2 * (size_t)(N + M);
+  float* gxy = gxx + (size_t)N * D;
+  hipLaunchKernelGGL(dense_logw_kernel, dim3((N + 255) / 256), dim3(256), 0, st, alpha, la, N);
+  hipLaunchKernelGGL(dense_logw_kernel, dim3((M + 255) / 256), dim3(256), 0, st, beta, lb, M);
+  // epsilon schedule in double, like the reference's python floats (geomloss epsilon_schedule, p = 2)
+  if (diameter < 1e-12) diameter = 1e-12;
+  const double e_start = 2.0 * log(diameter), e_stop = 2.0 * log((double)blur), e_step = 2.0 * log((double)scaling);
+  int n_ar = 0;
+  if (e_step < 0.0 && e_start > e_stop) n_ar = (int)ceil((e_stop - e_start) / e_step);
+  if (n_ar < 0) n_ar = 0;
+  if (n_ar > 4096) n_ar = 4096;
+  const int n_eps = n_ar + 2;
+  const double rho = reach > 0.f ? (double)reach * (double)reach : -1.0;
+  auto eps_at = [&](int i) -> double {
+    if (i == 0) return diameter * diameter;
+    if (i <= n_ar) return exp(e_start + (double)(i - 1) * e_step);
+    return (double)blur * (double)blur;
+  };
+  const int nmax = N > M ? N : M;
+  const dim3 grid((nmax + kRows - 1) / kRows, 4);
+  DenseArgs a;
+  a.x = x; a.y = y; a.la = la; a.lb = lb; a.N = N; a.M = M; a.grad_xx = gxx; a.grad_xy = gxy;
+  float* cur = potA;
+  float* nxt = potB;
+  auto launch = [&](int mode, double eps, bool grad) {
+    a.pot_old = cur; a.pot_new = nxt; a.mode = mode; a.eps = (float)eps;
+    a.lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
+    if (grad) hipLaunchKernelGGL((dense_softmin_kernel<D, true>), grid, dim3(kThreadsD), 0, st, a);
+    else hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
+    float* t = cur; cur = nxt; nxt = t;
+  };
+  launch(0, eps_at(0), false);
+  double eps = eps_at(0);
+  for (int it = 0; it < n_eps; ++it) {
+    eps = eps_at(it);
+    launch(1, eps, false);
+  }
+  launch(2, eps, true);
+  const float lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return KD6D_ERR_LAUNCH;
+  int nb = (nmax + 255) / 256;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(dense_finalize_kernel<D>, dim3(nb), dim3(256), 0, st, alpha, beta, cur, N, M, (float)eps, lam,
+                     (float)rho, gxx, gxy, loss, gx, galpha);
+  return KD6D_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t kd6d_sinkhorn_dense_workspace_floats(int N, int M, int D) {
+  return (int64_t)N + M + 4 * ((int64_t)N + M) + 2 * (int64_t)N * D + 64;
+}
+
+extern "C" int kd6d_sinkhorn_dense_diameter(const float* x, const float* y, int N, int M, int D, float* scratch64,
+                                            float* diam_out, void* stream) {
+  KD6D_CHECK_ARG(x && y && scratch64 && diam_out && N > 0 && M > 0, "kd6d_sinkhorn_dense_diameter: bad arguments");
+  KD6D_CHECK_ARG(D == 2 || D == 4 || D == 8 || D == 16, "kd6d_sinkhorn_dense_diameter: D=%d (supported: 2, 4, 8, 16)", D);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // ordered-int encodings of +inf / -inf
+  int init[64];
+  for (int i = 0; i < 32; ++i) { init[i] = 0x7f800000; init[32 + i] = (int)0xff800000 ^ 0x7fffffff; }
+  if (hipMemcpyAsync(scratch64, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) {
+    kd6d_set_error("kd6d_sinkhorn_dense_diameter: memcpy failed");
+    return KD6D_ERR_LAUNCH;
+  }
+  int nb = (int)(((long long)N * D + 1023) / 1024);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(dense_minmax_kernel, dim3(nb), dim3(256), 0, st, x, (long long)N, D, scratch64, scratch64 + 32);
+  nb = (int)(((long long)M * D + 1023) / 1024);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(dense_minmax_kernel, dim3(nb), dim3(256), 0, st, y, (long long)M, D, scratch64, scratch64 + 32);
+  hipLaunchKernelGGL(dense_diam_kernel, dim3(1), dim3(64), 0, st, scratch64, scratch64 + 32, D, diam_out);
+  KD6D_CHECK_LAUNCH("kd6d_sinkhorn_dense_diameter");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_sinkhorn_dense_fwd_bwd(const float* x, const float* alpha, const float* y, const float* beta,
+                                           int N, int M, int D, float p, float blur, float scaling, float reach,
+                                           double diameter, float* workspace, int64_t workspace_floats,
+                                           float* loss, float* grad_x, float* grad_alpha, void* stream) {
+  KD6D_CHECK_ARG(x && alpha && y && beta && workspace && loss && grad_x && grad_alpha,
+                 "kd6d_sinkhorn_dense_fwd_bwd: null pointer");
+  KD6D_CHECK_ARG(N > 0 && M > 0, "kd6d_sinkhorn_dense_fwd_bwd: empty set");
+  if (p != 2.0f) {
+    kd6d_set_error("kd6d_sinkhorn_dense_fwd_bwd: only p=2 is implemented (got %g)", (double)p);
+    return KD6D_ERR_UNSUPPORTED;
+  }
+  KD6D_CHECK_ARG(blur > 0.f && scaling > 0.f && scaling < 1.f && diameter > 0.0,
+                 "kd6d_sinkhorn_dense_fwd_bwd: need blur>0, 0<scaling<1 and the diameter of the point cloud "
+                 "(kd6d_sinkhorn_dense_diameter, or the caller's bound as with geomloss' diameter= argument)");
+  KD6D_CHECK_ARG(workspace_floats >= kd6d_sinkhorn_dense_workspace_floats(N, M, D),
+                 "kd6d_sinkhorn_dense_fwd_bwd: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  switch (D) {
+    case 2: rc = run_dense<2>(x, alpha, y, beta, N, M, blur, scaling, reach, diameter, workspace, loss, grad_x, grad_alpha, st); break;
+    case 4: rc = run_dense<4>(x, alpha, y, beta, N, M, blur, scaling, reach, diameter, workspace, loss, grad_x, grad_alpha, st); break;
+    case 8: rc = run_dense<8>(x, alpha, y, beta, N, M, blur, scaling, reach, diameter, workspace, loss, grad_x, grad_alpha, st); break;
+    case 16: rc = run_dense<16>(x, alpha, y, beta, N, M, blur, scaling, reach, diameter, workspace, loss, grad_x, grad_alpha, st); break;
+    default:
+      kd6d_set_error("kd6d_sinkhorn_dense_fwd_bwd: D=%d (supported: 2, 4, 8, 16)", D);
+      return KD6D_ERR_UNSUPPORTED;
+  }
+  if (rc) { kd6d_set_error("kd6d_sinkhorn_dense_fwd_bwd: memset failed"); return rc; }
+  KD6D_CHECK_LAUNCH("kd6d_sinkhorn_dense_fwd_bwd");
+  return KD6D_OK;
+}

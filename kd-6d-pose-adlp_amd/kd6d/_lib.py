@@ -71,6 +71,9 @@ SIGNATURES = {
     "kd6d_image_to_nhwc": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
     "kd6d_sinkhorn_div_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P],
     "kd6d_sinkhorn_max_points": [],
+    "kd6d_sinkhorn_dense_workspace_floats": [_I, _I, _I],
+    "kd6d_sinkhorn_dense_diameter": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "kd6d_sinkhorn_dense_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _D, _P, _I64, _P, _P, _P, _P],
     "kd6d_teacher_select": [_L, _P, _P, _P, _F, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "kd6d_ssc_assign": [_L, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "kd6d_focal_fwd": [_P, _P, _I, _F, _F, _P, _P],
@@ -103,7 +106,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith("_workspace_floats") else ctypes.c_int
     if lib.kd6d_abi_version() != ABI_VERSION:
         raise ImportError("libkd6d.so ABI version %d != expected %d" % (lib.kd6d_abi_version(), ABI_VERSION))
     return lib

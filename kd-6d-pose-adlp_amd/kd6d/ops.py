@@ -267,3 +267,29 @@ def sinkhorn_div(xs, alpha, s_start, s_cnt, yt, beta, t_start, t_cnt, n_images, 
                                         reach if reach is not None else -1.0, _ptr(loss), _ptr(valid),
                                         _ptr(gx), _ptr(ga), _stream()), "kd6d_sinkhorn_div_fwd_bwd")
     return loss, valid, gx, ga
+
+
+def sinkhorn_dense(x, alpha, y, beta, blur=0.05, scaling=0.5, reach=0.5, diameter=None, p=2.0):
+    """Debiased (unbalanced) Sinkhorn divergence between two LARGE weighted point sets: x (N,D), alpha (N),
+    y (M,D), beta (M), D in {2,4,8,16} -- losses/kd_loss.py:26-30 / loss_libs.py:47 with a dense grid of local
+    predictions (BASELINE config 5).  Returns loss (1,), dS/dx (N,D), dS/dalpha (N).
+    diameter=None reproduces geomloss' default: it is measured on the device and read back (one sync, like
+    the reference's `.item()`); pass a float (geomloss' diameter= argument) to stay asynchronous."""
+    N, D = x.shape
+    M = y.shape[0]
+    dev = x.device
+    assert x.dtype == torch.float32 and y.shape == (M, D) and alpha.shape == (N,) and beta.shape == (M,)
+    nws = int(lib.kd6d_sinkhorn_dense_workspace_floats(N, M, D))
+    ws = torch.empty(nws, dtype=torch.float32, device=dev)
+    if diameter is None:
+        d = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib.kd6d_sinkhorn_dense_diameter(_ptr(x), _ptr(y), N, M, D, _ptr(ws), _ptr(d), _stream()),
+              "kd6d_sinkhorn_dense_diameter")
+        diameter = float(d.item())
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    gx = torch.empty_like(x)
+    ga = torch.empty_like(alpha)
+    check(lib.kd6d_sinkhorn_dense_fwd_bwd(_ptr(x), _ptr(alpha), _ptr(y), _ptr(beta), N, M, D, p, blur, scaling,
+                                          reach if reach is not None else -1.0, float(max(diameter, 1e-12)), _ptr(ws), nws,
+                                          _ptr(loss), _ptr(gx), _ptr(ga), _stream()), "kd6d_sinkhorn_dense_fwd_bwd")
+    return loss, gx, ga

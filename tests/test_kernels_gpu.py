@@ -443,6 +443,96 @@ def test_sinkhorn_kernel_vs_oracle(gpu_device, reach):
     np.testing.assert_allclose(ga.cpu().numpy(), ga_r, rtol=2e-3, atol=2e-3 * np.abs(ga_r).max())
 
 
+def _dense_problem(N, M, D, seed, reach):
+    """ZebraPose-like dense local predictions: D-dim code probabilities sigmoid(N(0,2)) per cell, weighted by a
+    segmentation score sigmoid(N(0,2)); a few cells carry zero weight (background)."""
+    r = np.random.default_rng(seed)
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    x = sig(r.normal(0, 2, (N, D))).astype(np.float32)
+    y = (sig(r.normal(0, 2, (M, D))) * 0.9 + 0.05).astype(np.float32)
+    a = sig(r.normal(0, 2, N)).astype(np.float32)
+    b = sig(r.normal(0, 2, M)).astype(np.float32)
+    a[17::17] = 0.0
+    b[13::13] = 0.0
+    if reach is None:
+        a /= a.sum(); b /= b.sum()
+    return x, a, y, b
+
+
+@pytest.mark.parametrize("case", [
+    # (N, M, D, blur, reach)
+    (300, 257, 16, 0.05, 0.5),        # ragged sizes (not multiples of the 64-column tile / 256-row workgroup)
+    (130, 520, 16, 0.001, 0.5),       # the reference's blur: eps = 1e-6
+    (200, 200, 2, 0.01, None),        # balanced
+    (1000, 700, 8, 0.05, 0.5),
+    (64, 1, 4, 0.05, 0.5),            # a single target point
+])
+def test_sinkhorn_dense_kernel_vs_oracle(gpu_device, case):
+    """Dense (online-logsumexp) Sinkhorn kernel, fp32, vs the fp64 oracle: loss rtol 2e-4, gradients 5e-3 of
+    their scale (the fp32-vs-fp64 spread of the algorithm itself is 2e-6 / 4e-4)."""
+    ops = _ops()
+    from oracle.sinkhorn_ref import sinkhorn_divergence
+    N, M, D, blur, reach = case
+    x, a, y, b = _dense_problem(N, M, D, N + M, reach)
+    S_r, gx_r, ga_r = sinkhorn_divergence(a[None].astype(np.float64), x[None].astype(np.float64),
+                                          b[None].astype(np.float64), y[None].astype(np.float64), blur=blur,
+                                          scaling=0.5, reach=reach, with_grad=True)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    loss, gx, ga = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss.cpu().numpy(), S_r, rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_r[0], rtol=5e-3, atol=5e-3 * np.abs(gx_r).max())
+    np.testing.assert_allclose(ga.cpu().numpy(), ga_r[0], rtol=5e-3, atol=5e-3 * np.abs(ga_r).max())
+    # the caller-supplied diameter (geomloss' diameter= argument) gives the same schedule as the measured one
+    from oracle.sinkhorn_ref import max_diameter
+    loss2, _, _ = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach,
+                                     diameter=max_diameter(x[None], y[None]))
+    assert float(loss2) == pytest.approx(float(loss), rel=1e-5)
+
+
+def test_sinkhorn_dense_agrees_with_small_set_kernel(gpu_device):
+    """The two independent HIP implementations (per-image 8-wave kernel, dense tiled kernel) agree on a
+    problem both can run."""
+    ops = _ops()
+    N, M = 90, 70
+    x, a, y, b = _dense_problem(N, M, 2, 5, 0.5)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    loss_d, gx_d, ga_d = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=0.001, scaling=0.5, reach=0.5)
+    xs = np.repeat(x[:, None, :], 8, 1).copy(); ys = np.repeat(y[:, None, :], 8, 1).copy()
+    al = np.repeat(a[:, None], 8, 1).copy(); be = np.repeat(b[:, None], 8, 1).copy()
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=gpu_device)
+    loss_s, valid, gx_s, ga_s = ops.sinkhorn_div(t(xs), t(al), i32([0]), i32([N]), t(ys), t(be), i32([0]), i32([M]),
+                                                 1, 2.0, 0.001, 0.5, 0.5)
+    torch.cuda.synchronize()
+    assert int(valid[0]) == 1
+    assert float(loss_s[0]) == pytest.approx(8.0 * float(loss_d), rel=2e-4)
+    np.testing.assert_allclose(gx_s[:, 0].cpu().numpy(), gx_d.cpu().numpy(), rtol=5e-3,
+                               atol=5e-3 * float(gx_d.abs().max()))
+    np.testing.assert_allclose(ga_s[:, 0].cpu().numpy(), ga_d.cpu().numpy(), rtol=2e-3,
+                               atol=2e-3 * float(ga_d.abs().max()))
+
+
+@pytest.mark.parametrize("blur", [0.05, 0.001])
+def test_sinkhorn_dense_full_grid_properties(gpu_device, blur):
+    """BASELINE config 5 at full size -- N = M = 128*128 cells, 16-D codes -- where no CPU oracle (nor the
+    reference: geomloss would need KeOps) can go: size-independent properties of the divergence.
+    S(a,a) = 0 with zero gradient, S(a,b) = S(b,a), S > 0 for different clouds, finite gradients."""
+    ops = _ops()
+    N = M = 128 * 128
+    x, a, y, b = _dense_problem(N, M, 16, 1, 0.5)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    S_ab, gx, ga = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=0.5)
+    S_ba, _, _ = ops.sinkhorn_dense(t(y), t(b), t(x), t(a), blur=blur, scaling=0.5, reach=0.5)
+    S_aa, gx0, _ = ops.sinkhorn_dense(t(x), t(a), t(x), t(a), blur=blur, scaling=0.5, reach=0.5)
+    torch.cuda.synchronize()
+    s_ab, s_ba, s_aa = float(S_ab), float(S_ba), float(S_aa)
+    assert np.isfinite([s_ab, s_ba, s_aa]).all() and bool(torch.isfinite(gx).all()) and bool(torch.isfinite(ga).all())
+    assert s_ab > 0
+    assert s_ba == pytest.approx(s_ab, rel=2e-4)
+    assert abs(s_aa) <= 1e-4 * s_ab
+    assert float(gx0.abs().max()) <= 1e-3 * float(gx.abs().max())
+
+
 def test_fused_clip_adamw_matches_torch(gpu_device):
     """kd6d_sumsq + kd6d_clip_adamw vs clip_grad_norm_ + torch.optim.AdamW (train_libs.py:119 settings)
     over several steps on identical gradients, and vs the reference capture tests/golden/optim.npz."""
