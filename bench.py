@@ -193,9 +193,17 @@ def main():
             a[0] += 1; a[1] += f; a[2] += m
         peak = PEAK_BF16 if args.precision == "bf16" else PEAK_F32
         achieved = tot_flop / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(HERE, "profiles", "r01_conv_hbm_traffic.json")
+        if os.path.exists(tpath) and args.student == "darknet_tiny_h" and not full and B == 16 and args.precision == "bf16":
+            # HBM bytes of the conv family per step from rocprofv3 PMC passes (tools/pmc_traffic.sh, FETCH_SIZE x2
+            # per the gfx950 correction + WRITE_SIZE), committed with the profile it was taken from
+            with open(tpath) as f:
+                traffic = json.load(f)["conv_family_hbm_MB_per_step"] * 1e6
         roof = {"bound": "mfma", "kernel": "conv_igemm (fwd+dgrad+wgrad, all launches of a step)",
                 "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None, "launches_per_step": len(conv) // n_instr,
+                "traffic": traffic, "traffic_unit": "HBM bytes per step, conv family (PMC, profiles/r01_conv_hbm_traffic.json)",
+                "launches_per_step": len(conv) // n_instr,
                 "avg_launch_us": 1e3 * tot_ms / max(len(conv), 1),
                 "conv_ms_per_step": tot_ms / n_instr, "flop_per_step": tot_flop / n_instr,
                 "by_kind": {k: {"launches_per_step": v[0] // n_instr, "tflops": v[1] / (v[2] * 1e-3) / 1e12 if v[2] else 0,
