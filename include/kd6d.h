@@ -240,6 +240,16 @@ int kd6d_sinkhorn_dense_fwd_bwd(const float* x, const float* alpha, const float*
                                 float* workspace, int64_t workspace_floats, float* loss, float* grad_x,
                                 float* grad_alpha, void* stream);
 
+/* ---- Dynamic-Zoom-In front-end (the stage before the hot path): replaces
+ * transform.py:299-308 (Normalize, ToTensor) + dzi_libs.py:55-95,142-210 (affine from the jittered box,
+ * cv2.warpAffine bilinear on the image / nearest on the mask) for a whole batch.
+ * frames_bgr (B,H,W,3) uint8 as decoded; masks (B,H,W) float or NULL; center_scale (B,3) = {cx, cy, box side}
+ * (host: aug_bbox_DZI); lut_rgb (3,256) = float32((v/255 - mean_c)/std_c), RGB order.
+ * Out: images_nchw (B,3,out,out) fp32, masks_out (B,out,out), bbox_trans (B,2,3), bbox_scale (B) = out/side. */
+int kd6d_dzi_crop(const uint8_t* frames_bgr, const float* masks, int B, int H, int W, const float* center_scale,
+                  const float* lut_rgb, int out_res, float* images_nchw, float* masks_out, float* bbox_trans,
+                  float* bbox_scale, void* stream);
+
 /* ---- optimiser: replaces clip_grad_norm_ + AdamW.step of train_kd.py:138-139 on one flat buffer.
  * kd6d_sumsq accumulates sum(x^2) into *out (pre-zeroed); kd6d_clip_adamw applies
  * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update

@@ -83,6 +83,7 @@ SIGNATURES = {
     "kd6d_kd_mean": [_P, _P, _I, _P, _P, _P],
     "kd6d_loss_backward": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I,
                            _P, _P, _P],
+    "kd6d_dzi_crop": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P],
     "kd6d_sumsq": [_P, _I64, _P, _P],
     "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
     "kd6d_set_hyper": [_P, _D, _D, _D, _I64, _P],

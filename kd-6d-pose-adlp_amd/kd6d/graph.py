@@ -135,10 +135,11 @@ class GraphedKDStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_step):
+        # thread-local capture mode: with a process group alive, RCCL's watchdog thread polls events concurrently
+        with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
             self.losses = self._forward_backward()
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, pool=self.g_step.pool()):
+        with torch.cuda.graph(self.g_opt, pool=self.g_step.pool(), capture_error_mode="thread_local"):
             self.opt.launch(device_schedule=True)
         self._restore(snap)
 
