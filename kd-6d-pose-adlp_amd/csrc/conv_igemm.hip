@@ -1548,7 +1548,7 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
 template <int MODE>
 bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
   static const int force = []() {
-    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128 (8 waves), 2 = 128x128 (4 waves)
+    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128, 2 = 128x128 (4 waves), 3 = 128x128, 4 = 128x64
     return e ? atoi(e) : -1;
   }();
   if (force == 0) return false;
@@ -1562,16 +1562,22 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   }
   if (wmax > 64) return false;
   const int halo = wmax + 1;
-  // measured on the step's layers (tools/bench_conv.py): the 8-wave 256x128 tile wins once it yields
-  // >= 150 workgroups, the 4-wave 128x128 tile from >= 250; below that the tail of the last round
-  // outweighs the saved L2 traffic and the generic kernel's smaller tiles are faster
-  const int ct = (p.N + 127) / 128;
+  // measured on the step's layers (tools/bench_conv.py), all variants with 8 waves (2 per SIMD: with 4 waves
+  // the same 128x128 tile is 25-40 % slower, one wave per SIMD cannot hide the LDS-DMA / fragment latency):
+  //   256x128 once it yields >= 150 workgroups (teacher head, stage 2);
+  //   128x128 from >= 160 workgroups (teacher stage 3, FPN 32x32 level, student head towers fwd + dgrad);
+  //   128x64  from >= 64 workgroups (teacher stages 4/5, FPN 16x16 level, student FPN) -- ahead of split-K;
+  // below that the layer goes to split-K / the generic kernels.
+  const int pt128 = (p.M + 127) / 128;
   int pick = 0;
-  if (((p.M + 255) / 256) * ct >= 150) pick = 1;
-  else if (((p.M + 127) / 128) * ct >= 250) pick = 2;
+  if (((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
+  else if (pt128 * ((p.N + 127) / 128) >= 160) pick = 3;
+  else if (pt128 * ((p.N + 63) / 64) >= 64) pick = 4;
   if (force > 0) pick = force;
   if (pick == 0) return false;
   if (pick == 1) launch_halo<256, 128, 4, 2, MODE>(p, halo, rows, st);
+  else if (pick == 3) launch_halo<128, 128, 4, 2, MODE>(p, halo, rows, st);      // 8 waves on the 128x128 tile
+  else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);
   else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
   return true;
 }
@@ -1783,8 +1789,9 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    if (!dispatch_splitk<MODE_FWD>(p, reinterpret_cast<float*>(workspace), (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), st) &&
-        !dispatch_halo<MODE_FWD>(p, g, st) && !dispatch_glds<MODE_FWD>(p, st))
+    if (!dispatch_halo<MODE_FWD>(p, g, st) &&
+        !dispatch_splitk<MODE_FWD>(p, reinterpret_cast<float*>(workspace), (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), st) &&
+        !dispatch_glds<MODE_FWD>(p, st))
       dispatch_igemm<bf16_t, MODE_FWD>(p, st);
   } else {
     dispatch_igemm<float, MODE_FWD>(p, st);
