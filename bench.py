@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--no-pipeline", action="store_true",
                    help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
+    p.add_argument("--teacher-group", type=int, default=1,
+                   help="pipelined mode: run the frozen teacher once per group of this many incoming batches "
+                        "(1 = once per batch); the student always steps on single batches of --batch images")
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--layer-table", type=str, default="", help="write the per-launch conv table (instrumented steps) here")
     return p.parse_args()
@@ -121,18 +124,27 @@ def main():
         images, targets = make_batch(B, 1000 * rank + i, full_frame=full)
         batches.append((images.to(dev), PackedTargets(targets, dev)))
 
-    from kd6d.graph import GraphedKDStep
-    gstep = None if args.no_graph else GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0),
-                                                     pipeline=not args.no_pipeline)
+    from kd6d.graph import GraphedKDStep, GroupedKDStep
+    if args.no_graph:
+        gstep = None
+    elif not args.no_pipeline and args.teacher_group > 1:
+        gstep = GroupedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=args.teacher_group)
+    else:
+        gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
+    n_prime = 0
     if gstep is not None and gstep.pipeline:
-        gstep(*batches[0])          # priming call: teacher cells of the first batch, no student step yet
+        # priming calls (teacher only, no student step yet): 1 for the per-batch pipeline, G for the grouped one
+        while gstep(*batches[n_prime % len(batches)]) is None:
+            n_prime += 1
+            assert n_prime <= 64
+        n_prime += 1
 
     def step(i, eager=False):
         images, tgt = batches[i % len(batches)]
         if gstep is not None and not eager:
             # pipelined: this call runs the teacher on batch i+1 beside the student step on batch i
             # (one teacher forward and one student step per call either way)
-            ld = gstep(*batches[(i + 1) % len(batches)]) if gstep.pipeline else gstep(images, tgt)
+            ld = gstep(*batches[(i + n_prime) % len(batches)]) if gstep.pipeline else gstep(images, tgt)
             sched.step()
             return ld
         student._defer_allreduce = False
@@ -218,7 +230,10 @@ def main():
                                               "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
                           "global_batch": B * world, "parallelism": "dp%d" % world,
                           "launch": "eager" if gstep is None else ("hipGraph replay (2 graphs/step)" + (
-                              ", teacher(k+1) overlapped with student step(k)" if gstep.pipeline else "")),
+                              "" if not gstep.pipeline else
+                              ", teacher(k+1) overlapped with student step(k)" if not hasattr(gstep, "G") else
+                              ", frozen teacher run once per %d incoming batches (%d images) on its own stream, "
+                              "student steps on single batches" % (gstep.G, gstep.G * B))),
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
                "losses_last_step": losses, "finite": finite, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
                "roofline": roof}

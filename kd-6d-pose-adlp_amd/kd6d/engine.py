@@ -446,7 +446,7 @@ class PoseNet:
             self._bufs[key] = b
         return b
 
-    SCRATCH_FLOATS = 1 << 18
+    SCRATCH_FLOATS = 1 << 21
     WORKSPACE_BYTES = 64 << 20      # split-K partial slabs (fp32) of the few-tile / long-K layers
 
     def workspace(self):
@@ -458,10 +458,10 @@ class PoseNet:
 
     def scratch(self, name, n):
         """fp32 slice of the per-step scratch arena (zeroed once per step by the training forward)."""
-        off = self._scratch_off.get(name)
+        off = self._scratch_off.get((name, n))          # per (name, size): the same net may run several batch sizes
         if off is None:
             off = self._scratch_size
-            self._scratch_off[name] = off
+            self._scratch_off[(name, n)] = off
             self._scratch_size += (n + 7) // 8 * 8
             assert self._scratch_size <= self.SCRATCH_FLOATS, "scratch arena too small"
         if self.scratch_buf is None:
@@ -529,7 +529,8 @@ class PoseNet:
         self.prepare_weights(need_dgrad=self.training)
         self.tape = []
         if self.scratch_buf is not None:
-            self.scratch_buf.zero_()         # one memset per step: every atomically accumulated statistic lives here
+            # one memset per step: every atomically accumulated statistic lives here (only the part in use)
+            self.scratch_buf[:max(self._scratch_size, 8)].zero_()
         x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=self.buf("input", (B * H * W, 8)))
         feats = self._backbone53(x, B, [(H, W)]) if self.arch == "darknet53" else self._backbone_tiny(x, B, [(H, W)])
         oc = self.out_channel

@@ -105,6 +105,17 @@ class PackedTargets:
         self.flat_f.copy_(other.flat_f, non_blocking=True)
         self.flat_i.copy_(other.flat_i, non_blocking=True)
 
+    @staticmethod
+    def teacher_view(tgt, groups):
+        """What the teacher's forward reads of the targets (the crop affines, postprocess_kd.py:171-179) for
+        `groups` batches back to back."""
+        out = object.__new__(PackedTargets)
+        out.batch = tgt.batch * groups
+        out.bbox_trans = tgt.bbox_trans.new_zeros((out.batch, 2, 3))
+        out.frame_wh = tgt.frame_wh
+        out.mask_h, out.mask_w = tgt.mask_h, tgt.mask_w
+        return out
+
 
 class TeacherKnowledge(dict):
     """pred_t of the reference (models/model_kd.py:83-92).  The device-side slot arrays are what the
@@ -124,6 +135,30 @@ class TeacherKnowledge(dict):
         n, b = self.batch * self.cap, self.batch
         return TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
                                 wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), self.cap, b, (wf, wi))
+
+    def slice_static(self, j, groups):
+        """Persistent TeacherKnowledge for ONE batch out of a result computed on `groups` batches at once."""
+        b = self.batch // groups
+        n = b * self.cap
+        wf = self.flats[0].new_zeros(n * 48)
+        wi = self.flats[1].new_zeros(n + (b + 3) // 4 * 4)
+        out = TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
+                               wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), self.cap, b, (wf, wi))
+        out.copy_slice_from(self, j, groups)
+        return out
+
+    def copy_slice_from(self, big, j, groups):
+        """self (one batch) <- rows of batch j of `big` (computed on `groups` batches)."""
+        b, cap = self.batch, self.cap
+        n, N = b * cap, big.batch * big.cap
+        r0 = j * n
+        sf, bf = self.flats[0], big.flats[0]
+        for width, s_off, b_off in ((16, 0, 0), (16, n * 16, N * 16), (8, n * 32, N * 32), (8, n * 40, N * 40)):
+            sf[s_off:s_off + n * width].copy_(bf[b_off + r0 * width:b_off + (r0 + n) * width], non_blocking=True)
+        self.t_row.copy_(big.t_row[r0:r0 + n], non_blocking=True)
+        self.t_cnt.copy_(big.t_cnt[j * b:(j + 1) * b], non_blocking=True)
+        for key in ("post_kp_2d", "post_kp_cls", "post_pos_per_img"):
+            self.pop(key, None)
 
     def copy_from(self, other):
         for mine, theirs in zip(self.flats, other.flats):
