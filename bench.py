@@ -42,8 +42,8 @@ PEAK_F32 = 157.3e12
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch", type=int, default=16, help="images per GPU")
     p.add_argument("--student", type=str, default="darknet_tiny_h")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
@@ -149,6 +149,7 @@ def main():
             return ld
         student._defer_allreduce = False
         student.net.side_stream = None        # per-launch HIP-event timing wants one kernel at a time
+        student.net.side_streams = None
         student.zero_grad()
         with torch.no_grad():
             pred_t = teacher(images, targets=tgt, is_teacher=True)

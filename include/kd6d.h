@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 2
+#define KD6D_ABI_VERSION 3
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -91,9 +91,12 @@ int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void* dy,
 
 /* dw[cout][ky][kx][cin] += sum_pixels dy (x) x   (fp32 atomics, dw pre-zeroed
  * or holding a running sum).  dbias (optional): dbias[cout] += sum_pixels dy, the bias gradient of
- * the same layer, taken from the dY tiles the kernel stages anyway. */
+ * the same layer, taken from the dY tiles the kernel stages anyway.
+ * cu_budget: how many compute units this launch should aim to fill (0 = the whole device).  The pixel
+ * axis is split over workgroups and every split ends in an atomic flush of its dW tile, so a caller that
+ * keeps k weight gradients in flight on k streams passes CUs/k: same k-loop work, 1/k of the flushes. */
 int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x,
-                      const void* dy, float* dw, float* dbias, void* stream);
+                      const void* dy, float* dw, float* dbias, int cu_budget, void* stream);
 
 /* wt[cin][ky][kx][cout] <- w[cout][ky][kx][cin] for n_layers layers in one
  * launch.  desc_dev: int32[n_layers*6] = {w_off, wt_off, cout, cin, ksize,

@@ -977,6 +977,7 @@ struct WgradParams {
   const void* dy;
   float* dw;
   float* dbias;   // optional: += column sums of dY (bias gradient), accumulated by the j-tile-0 workgroups
+  int cu_budget;  // CUs this launch should aim to fill (callers that run several weight gradients side by side)
 };
 
 template <typename T>
@@ -1706,6 +1707,11 @@ void launch_wgrad(const WgradParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, st, q);
 }
 
+int cached_cu_count() {       // one device per process
+  static const int n = []() { const int c = kd6d_device_cu_count(); return c > 0 ? c : 256; }();
+  return n;
+}
+
 template <int BN, int WN, int WJ>
 void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
   constexpr int BJ = 128, BKM = 64;
@@ -1721,8 +1727,11 @@ void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
     const char* e = getenv("KD6D_WGRAD_SPLIT_SCALE");
     return e ? atof(e) : 1.0;
   }();
+  // a caller that keeps several weight gradients in flight asks each for a fraction of the device: fewer,
+  // longer splits -> proportionally fewer atomic tile flushes for the same k-loop work
+  const double frac = (double)p.cu_budget / (double)cached_cu_count();
   const double dw_bytes = (double)p.Cout * (double)p.J * 4.0;
-  int splits = (int)(scale * sqrt((double)steps_total * 2.08e6 / dw_bytes) + 0.5);
+  int splits = (int)(scale * frac * sqrt((double)steps_total * 2.08e6 / dw_bytes) + 0.5);
   if (splits > 512 / tiles) splits = 512 / tiles;
   if (splits > steps_total / 2) splits = steps_total / 2;
   if (splits < 1) splits = 1;
@@ -1829,7 +1838,7 @@ extern "C" int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void*
 extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum, float* sumsq, void* stream);
 
 extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy,
-                                 float* dw, float* dbias, void* stream) {
+                                 float* dw, float* dbias, int cu_budget, void* stream) {
   int rc = check_geom(g, dtype, "kd6d_conv2d_wgrad");
   if (rc) return rc;
   KD6D_CHECK_ARG(x && dy && dw, "kd6d_conv2d_wgrad: null tensor pointer");
@@ -1845,6 +1854,9 @@ extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void*
     KD6D_CHECK_ARG(p.seg[s].dst_row0 == p.seg[s].m_begin,
                    "kd6d_conv2d_wgrad: output levels must be packed back to back");
   p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias;
+  const int ncu = cached_cu_count();
+  KD6D_CHECK_ARG(cu_budget >= 0, "kd6d_conv2d_wgrad: cu_budget=%d", cu_budget);
+  p.cu_budget = (cu_budget == 0 || cu_budget > ncu) ? ncu : cu_budget;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
     dispatch_wgrad_tr(p, st);

@@ -182,7 +182,7 @@ class Conv:
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
         st = self.net.store
         g = self.geom(batch, levels)
-        side = self.net.side_stream
+        side = self.net.next_side_stream()
         if side is None:
             ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
                              dbias=None if self.b is None else st.storage(self.b, "grads"))
@@ -193,7 +193,8 @@ class Conv:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
-                                 dbias=None if self.b is None else st.storage(self.b, "grads"))
+                                 dbias=None if self.b is None else st.storage(self.b, "grads"),
+                                 cu_budget=self.net.wgrad_cu_budget)
         if not need_dx:
             return None
         return ops.conv2d_dgrad(g, dy, self.weight_t(), dx=dx, accumulate=accumulate, flops=self.flops(g))
@@ -314,6 +315,9 @@ class PoseNet:
         self.wt = None
         self.training = True
         self.side_stream = None        # set (e.g. by GraphedKDStep) to run weight gradients concurrently
+        self.side_streams = None       # optional list: consecutive weight gradients rotate over these streams
+        self.wgrad_cu_budget = 0       # CUs each forked weight gradient aims to fill (0 = the device)
+        self._side_rr = 0
         feat, oc = BACKBONE_CFG[arch]
         self.out_channel = oc
         self.n_levels = 5 if arch == "darknet53" else 4
@@ -446,8 +450,14 @@ class PoseNet:
             self._bufs[key] = b
         return b
 
-    SCRATCH_FLOATS = 1 << 21
+    SCRATCH_FLOATS = 1 << 22
     WORKSPACE_BYTES = 64 << 20      # split-K partial slabs (fp32) of the few-tile / long-K layers
+
+    def next_side_stream(self):
+        if self.side_streams:
+            self._side_rr = (self._side_rr + 1) % len(self.side_streams)
+            return self.side_streams[self._side_rr]
+        return self.side_stream
 
     def workspace(self):
         ws = self._bufs.get("__workspace__")
@@ -667,6 +677,6 @@ class PoseNet:
                 grad = blk.bwd(rec, grad, need_dx=need_dx,
                                dx=self.buf(blk.name + ".dx", rec[1].shape) if need_dx else None)
             i_rec -= 1
-        if self.side_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
+        for side in (self.side_streams or ([self.side_stream] if self.side_stream is not None else [])):
+            torch.cuda.current_stream().wait_stream(side)
         return None

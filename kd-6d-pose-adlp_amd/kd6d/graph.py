@@ -23,20 +23,31 @@ teacher + student to max(teacher, student), and the two halves fill each other's
 """
 import torch
 
+from . import ops
 from .kd_losses import DeferredTeacher, PackedTargets
 from .libs import distributed as D
 from .libs.poses import ImageList
 
 
 class GraphedKDStep:
+    WGRAD_STREAMS = 4          # weight-gradient launches kept in flight beside the dgrad / normalisation chain
+
     def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3,
                  concurrent=True, pipeline=False):
         self.teacher, self.student, self.opt = teacher, student, optimizer
         # fork/join inside the captured graph: the teacher's forward runs beside the student's, and the weight
         # gradients beside the dgrad / normalisation chain (many of these kernels fill < 256 CUs on their own)
         self.teacher_stream = torch.cuda.Stream() if (concurrent or pipeline) else None
-        student.net.side_stream = torch.cuda.Stream() if concurrent else None
+        # ... with several weight gradients in flight, each sized for its share of the CUs: the same k-loop work
+        # with proportionally fewer atomic dW-tile flushes (measured: 1 -> 4 streams = +8 % on the step)
+        nside = self.WGRAD_STREAMS
+        snet = student.net
+        snet.side_stream = torch.cuda.Stream() if concurrent else None
+        snet.side_streams = ([snet.side_stream] + [torch.cuda.Stream() for _ in range(nside - 1)]
+                             if concurrent and nside > 1 else None)
+        snet.wgrad_cu_budget = (ops.device_cu_count() // nside) if concurrent and nside > 1 else 0
         self.w_cls, self.w_reg, self.w_kd = (float(w) for w in loss_weights)
+        self._w = None                                     # the same weights as a device tensor
         self.cfg_kd = cfg_kd
         self.warmup = warmup
         self.pipeline = pipeline
@@ -48,12 +59,11 @@ class GraphedKDStep:
 
     # ---- the body the reference's loop runs per iteration (train_kd.py:104-137) ----------
     def _student_step(self, pred_t):
-        _, ld = self.student(self.images, targets=self.tgt, pred_t=pred_t, cfg_kd=self.cfg_kd)
-        loss = ld["loss_cls"] * self.w_cls + ld["loss_reg"] * self.w_reg
-        if self.w_kd > 0.0:
-            loss = loss + ld["loss_kd"] * self.w_kd
-        loss.backward()
-        return {k: v.detach() for k, v in ld.items()}
+        if self._w is None:
+            self._w = torch.tensor([self.w_cls, self.w_reg, self.w_kd], dtype=torch.float32,
+                                   device=self.student.net.device)
+        losses = self.student.step_losses(self.images, self.tgt, pred_t, self._w)
+        return {"loss_cls": losses[0], "loss_reg": losses[1], "loss_kd": losses[2]}
 
     def _teacher(self, images, tgt):
         with torch.no_grad():

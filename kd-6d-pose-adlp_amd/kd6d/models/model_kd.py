@@ -170,19 +170,7 @@ class PoseModuleKD(nn.Module):
         B = x.shape[0]
         net = self.net
         if self.training:
-            st = net.store
-            st.ensure_grads()
-            cls, reg = net.forward(x)
-            tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
-            if isinstance(pred_t, kd_losses.DeferredTeacher):      # teacher ran concurrently on another stream
-                pred_t = pred_t.join()
-            teacher = pred_t if isinstance(pred_t, TeacherKnowledge) else None
-            if pred_t is not None and teacher is None:
-                raise TypeError("pred_t must come from a kd6d teacher forward (TeacherKnowledge)")
-            losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher,
-                                                 keys=getattr(self, "_debug_keys", None),
-                                                 seg_scale=st.storage(net.scales))
-            self._nbt += 1
+            losses = self._forward_losses(x, targets, pred_t)
             l_cls, l_reg, l_kd = _StepFn.apply(self._anchor, losses, self)
             return None, {"loss_cls": l_cls, "loss_reg": l_reg, "loss_kd": l_kd}
         if is_teacher:
@@ -192,6 +180,38 @@ class PoseModuleKD(nn.Module):
                                             self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh)
         raise NotImplementedError("eval-mode pose inference (postprocess/postprocess.py, RANSAC-EPnP) is outside the "
                                   "KD-step hot path (SURVEY.md 8(f)-2)")
+
+    def _forward_losses(self, x, targets, pred_t):
+        """Student forward + the three loss sums -> fp32[3] device tensor {cls, reg, kd} (unweighted)."""
+        net = self.net
+        B = x.shape[0]
+        st = net.store
+        st.ensure_grads()
+        cls, reg = net.forward(x)
+        tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
+        if isinstance(pred_t, kd_losses.DeferredTeacher):      # teacher ran concurrently on another stream
+            pred_t = pred_t.join()
+        teacher = pred_t if isinstance(pred_t, TeacherKnowledge) else None
+        if pred_t is not None and teacher is None:
+            raise TypeError("pred_t must come from a kd6d teacher forward (TeacherKnowledge)")
+        losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher,
+                                             keys=getattr(self, "_debug_keys", None),
+                                             seg_scale=st.storage(net.scales))
+        self._nbt += 1
+        return losses
+
+    def step_losses(self, images, targets, pred_t, weights):
+        """forward + backward of d(sum_i weights[i] * loss_i) without the autograd detour (the ~16 one-element
+        torch kernels that `(l_cls * w + ...).backward()` puts between the loss and the reverse sweep).
+        weights: fp32[3] device tensor.  Returns the fp32[3] loss tensor; gradients land in the flat bucket."""
+        if not self.training:
+            raise RuntimeError("step_losses() is the training step")
+        x = images.tensors if hasattr(images, "tensors") else images
+        if x.device != self.net.device:
+            raise RuntimeError("images are on %s but the model is on %s" % (x.device, self.net.device))
+        losses = self._forward_losses(x, targets, pred_t)
+        self._run_backward(weights)
+        return losses
 
     def _run_backward(self, weights):
         net, st = self.net, self.net.store

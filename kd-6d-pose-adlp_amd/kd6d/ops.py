@@ -131,15 +131,22 @@ def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     return dx
 
 
-def conv2d_wgrad(geom, x, dy, dw, flops=0, dbias=None):
+def conv2d_wgrad(geom, x, dy, dw, flops=0, dbias=None, cu_budget=0):
     assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
     assert x.dtype == dy.dtype and dw.dtype == torch.float32
     assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     with _Timed("conv_wgrad", flops, geom):
         assert dbias is None or (dbias.dtype == torch.float32 and dbias.numel() >= geom.cout)
-        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), _stream()),
-              "kd6d_conv2d_wgrad")
+        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), int(cu_budget),
+                                    _stream()), "kd6d_conv2d_wgrad")
     return dw
+
+
+def device_cu_count():
+    n = lib.kd6d_device_cu_count()
+    if n <= 0:
+        raise RuntimeError("kd6d_device_cu_count failed: %s" % lib.kd6d_last_error().decode())
+    return n
 
 
 def pack_dgrad_weights(w_base, wt_base, desc_dev, n_layers, total_blocks):

@@ -160,8 +160,17 @@ def test_conv_dgrad(gpu_device, dtype, case):
         torch.testing.assert_close(ga, ref + d0, **_tol(dtype, stored=True))
 
 
+WGRAD_EXTRA = [
+    # 128-wide dW tiles (the LDS-DMA ring kernel): several taps per 128-column row, partial j-tile, odd sizes
+    (2, 16, 128, 3, 1, [(32, 32)]),
+    (3, 32, 256, 3, 1, [(16, 16), (7, 5)]),
+    (2, 8, 72, 3, 2, [(33, 31)]),
+    (16, 128, 128, 3, 1, [(32, 32), (16, 16), (8, 8), (4, 4)]),     # the student head shape (many splits)
+]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("case", CONV_CASES + WGRAD_EXTRA)
 def test_conv_wgrad(gpu_device, dtype, case):
     ops = _ops()
     B, Cin, Cout, k, stride, levels = case
