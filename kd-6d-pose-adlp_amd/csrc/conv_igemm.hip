@@ -35,7 +35,16 @@ struct SegDev {
   int dst_row0;        // first destination row of the level
   int m_begin;         // first GEMM row index of the level
   int dst_hw;
+  float inv_hw, inv_w; // 1 / dst_hw, 1 / dst_w: row decode without integer division (GEMM rows < 2^24)
 };
+
+// floor(x / d) for 0 <= x < 2^24 from inv = 1.0f / d: float estimate, one correction step either way
+__device__ __forceinline__ int fast_div(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  q += ((q + 1) * d <= x) ? 1 : 0;
+  q -= (q * d > x) ? 1 : 0;
+  return q;
+}
 
 struct ConvParams {
   int nseg, batch;
@@ -62,7 +71,6 @@ struct ConvParams {
   float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
   int nk_split;        // k-steps per split
   int stats_cpg_shift; // log2(channels per group): 2 or 3
-  float seg_inv_hw[kMaxSeg];   // 1 / (dst_h * dst_w) per level (division-free image index)
 };
 
 template <typename T> struct Frag;
@@ -126,18 +134,19 @@ struct RowInfo {
 __device__ __forceinline__ RowInfo decode_row(const ConvParams& p, int m) {
   RowInfo r;
   int mb = 0, hw = 1, dw = 1, sh = 0, sw = 0, s0 = 0, d0 = 0, sg = 0;
+  float ihw = 1.f, iw = 1.f;
 #pragma unroll
   for (int s = 0; s < kMaxSeg; ++s) {
     if (s < p.nseg && m >= p.seg[s].m_begin) {
       mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; dw = p.seg[s].dst_w;
       sh = p.seg[s].src_h; sw = p.seg[s].src_w; s0 = p.seg[s].src_row0;
-      d0 = p.seg[s].dst_row0; sg = s;
+      d0 = p.seg[s].dst_row0; sg = s; ihw = p.seg[s].inv_hw; iw = p.seg[s].inv_w;
     }
   }
   const int local = m - mb;
-  const int b = local / hw;
+  const int b = fast_div(local, hw, ihw);
   const int rem = local - b * hw;
-  r.y = rem / dw;
+  r.y = fast_div(rem, dw, iw);
   r.x = rem - r.y * dw;
   r.src_h = sh; r.src_w = sw;
   r.src_base = s0 + b * sh * sw;
@@ -219,7 +228,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s)
       if (s < p.nseg && m >= p.seg[s].m_begin) {
-        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg_inv_hw[s];
+        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg[s].inv_hw;
       }
     // (m - mb) / hw without an integer division (operands < 2^24): float estimate, then one correction step
     const int xx = m - mb;
@@ -854,14 +863,12 @@ __global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvPar
     const RowInfo ri = decode_row(p, m);      // packed identically on both sides: src row == dst row == m
     pbase[q] = m - patch_lo;
     pw[q] = ri.src_w;
-    int mask = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = MODE == MODE_FWD ? t / 3 - 1 : 1 - t / 3;
-      const int dx = MODE == MODE_FWD ? t % 3 - 1 : 1 - t % 3;
-      const bool ok = (unsigned)(ri.y + dy) < (unsigned)ri.src_h && (unsigned)(ri.x + dx) < (unsigned)ri.src_w;
-      mask |= ok ? (1 << t) : 0;
-    }
+    // tap t = 3*ty + tx reads (y + dy, x + dx): three column bits, replicated into the valid rows
+    const int lo_x = ri.x > 0 ? 1 : 0, hi_x = ri.x + 1 < ri.src_w ? 1 : 0;
+    const int lo_y = ri.y > 0 ? 1 : 0, hi_y = ri.y + 1 < ri.src_h ? 1 : 0;
+    const int cols = MODE == MODE_FWD ? (lo_x | 2 | (hi_x << 2)) : (hi_x | 2 | (lo_x << 2));
+    const int r0 = MODE == MODE_FWD ? lo_y : hi_y, r2 = MODE == MODE_FWD ? hi_y : lo_y;
+    const int mask = (r0 ? cols : 0) | (cols << 3) | (r2 ? (cols << 6) : 0);
     pmask[q] = m < p.M ? mask : 0;
   }
 
@@ -956,6 +963,141 @@ __global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvPar
     }
   }
   conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, bf16, C in {8, 16, 32}: the wide, shallow layers at the top of both
+// backbones (up to a million pixels, K = 72..288).  They are bound by memory, not by MFMA: the
+// generic kernels fetch every input pixel nine times in 16-B granules (one per tap), pad K to a
+// multiple of 64 and pay a pixel decode per tile for two to five k-steps of work.
+// Here a workgroup owns 256 consecutive pixels: their input rows plus a halo (level width + 1 on
+// either side) and the WHOLE weight matrix land in LDS once (LDS-DMA, one wait), the im2col operand
+// never exists: the MFMA pixel fragment of k-chunk c is a 16-B read at patch row
+// (pixel + dy*W + dx) for the tap that lane's eight k-values belong to (k = tap*C + ci, so with
+// C = 8 one 32-deep MFMA spans four taps), out-of-image taps and the K padding read a zero row.
+// No pipeline inside the workgroup: several workgroups share a CU and overlap each other's phases.
+// ---------------------------------------------------------------------------
+template <int CG>
+__device__ __forceinline__ int smallc_swz(int row) {
+  return CG == 1 ? 0 : (CG == 2 ? ((row >> 3) & 1) : ((row >> 2) & 3));
+}
+
+template <int CG, int NB, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_smallc_kernel(const ConvParams p, int halo, int total_rows,
+                                                             int patch_bytes, int wbytes) {
+  using T = bf16_t;
+  constexpr int BP = 256;
+  constexpr int BC = 16 * NB;
+  constexpr int C = 8 * CG;
+  constexpr int KG = 9 * CG;                 // 16-B granules of one weight row
+  constexpr int NKC = (9 * C + 31) / 32;     // 32-deep k-chunks
+  constexpr int WG = NKC * 4 + 1;            // 16-B slots per weight row in LDS (odd multiple of 16 B mod 128: no bank conflicts)
+  constexpr int ROWB = 16 * CG;
+  constexpr int PI = 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const patch = smem;
+  char* const wlds = smem + patch_bytes;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_c = wg % p.n_ctiles;
+  const int tile_p = wg / p.n_ctiles;
+  const int m0 = tile_p * BP;
+  const int n0 = tile_c * BC;
+  const int patch_lo = m0 - halo;
+  const int prows = BP + 2 * halo;           // real patch rows; row `prows` is the zero row
+  const int zero_row = prows;
+
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+  const char* zero = reinterpret_cast<const char*>(kd6d_zero_page);
+
+  // ---- everything this workgroup reads, in one burst of LDS-DMA ----
+  {
+    const int pslots = patch_bytes >> 4;
+    for (int s0 = wave * 64; s0 < pslots; s0 += 256) {
+      const int s = s0 + lane;
+      const int prow = s / CG;                     // CG is a power of two
+      const int gs = s - prow * CG;
+      const int row = patch_lo + prow;
+      const void* g = zero;
+      if (prow < prows && row >= 0 && row < total_rows)
+        g = src + ((size_t)row * (size_t)C + (size_t)((gs ^ smallc_swz<CG>(prow)) * 8));
+      glds16(g, patch + s0 * 16);
+    }
+    constexpr int wslots = (BC * WG + 63) / 64 * 64;
+    for (int s0 = wave * 64; s0 < wslots; s0 += 256) {
+      const int s = s0 + lane;
+      const int n = s / WG;
+      const int gs = s - n * WG;
+      const void* g = zero;
+      if (n < BC && n0 + n < p.N && gs < KG) g = wgt + ((size_t)(n0 + n) * (size_t)p.K + (size_t)(gs * 8));
+      glds16(g, wlds + s0 * 16);
+    }
+  }
+
+  // ---- pixel state, one decode per pixel of the tile (thread t <-> pixel m0 + t), shared through LDS ----
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  int* const pinfo = reinterpret_cast<int*>(wlds + wbytes);      // tap validity (9 bits) | level width << 16
+  {
+    const int m = m0 + tid;
+    const RowInfo ri = decode_row(p, m);      // packed identically on both sides: src row == dst row == m
+    // tap t = 3*ty + tx reads (y + dy, x + dx): three column bits, replicated into the valid rows
+    const int lo_x = ri.x > 0 ? 1 : 0, hi_x = ri.x + 1 < ri.src_w ? 1 : 0;
+    const int lo_y = ri.y > 0 ? 1 : 0, hi_y = ri.y + 1 < ri.src_h ? 1 : 0;
+    const int cols = MODE == MODE_FWD ? (lo_x | 2 | (hi_x << 2)) : (hi_x | 2 | (lo_x << 2));
+    const int r0 = MODE == MODE_FWD ? lo_y : hi_y, r2 = MODE == MODE_FWD ? hi_y : lo_y;
+    const int mask = (r0 ? cols : 0) | (cols << 3) | (r2 ? (cols << 6) : 0);
+    pinfo[tid] = (m < p.M ? mask : 0) | (ri.src_w << 16);
+  }
+
+  f32x4_t acc[NB][PI];
+#pragma unroll
+  for (int c = 0; c < NB; ++c)
+#pragma unroll
+    for (int q = 0; q < PI; ++q) acc[c][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  int pbase[PI], pw[PI], pmask[PI];
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int pl = wave * 64 + q * 16 + fr;
+    const int info = pinfo[pl];
+    pbase[q] = pl + halo;                     // patch row of the pixel itself
+    pw[q] = info >> 16;
+    pmask[q] = info & 0x1ff;
+  }
+
+#pragma unroll
+  for (int ch = 0; ch < NKC; ++ch) {
+    const int kg = ch * 4 + fq;               // this lane's 16-B k-granule: tap kg / CG, channel granule kg % CG
+    const int tap = kg / CG;
+    const int cgr = kg - tap * CG;
+    const int ty = tap / 3;
+    const int dy = MODE == MODE_FWD ? ty - 1 : 1 - ty;
+    const int dx = MODE == MODE_FWD ? (tap - 3 * ty) - 1 : 1 - (tap - 3 * ty);
+    Frag<T> fa[NB], fb[PI];
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      fa[c].v = *reinterpret_cast<const bf16x8_t*>(wlds + ((c * 16 + fr) * WG + kg) * 16);
+#pragma unroll
+    for (int q = 0; q < PI; ++q) {
+      int r = pbase[q] + dy * pw[q] + dx;
+      r = (tap < 9 && ((pmask[q] >> tap) & 1)) ? r : zero_row;
+      fb[q].v = *reinterpret_cast<const bf16x8_t*>(patch + r * ROWB + ((cgr ^ smallc_swz<CG>(r)) << 4));
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+#pragma unroll
+      for (int q = 0; q < PI; ++q) mma(fa[c], fb[q], acc[c][q]);
+  }
+  conv_epilogue<T, BP, BC, 4, 1>(p, acc, m0, n0, wave, 0, lane, reinterpret_cast<float*>(smem));
 }
 
 // ---------------------------------------------------------------------------
@@ -1437,8 +1579,11 @@ bool fill_segs(const kd6d_conv_geom* g, bool dgrad, SegDev* seg, int* M_out) {
       d.src_row0 = gs.out_row0; d.dst_row0 = gs.in_row0;
     }
     d.dst_hw = d.dst_h * d.dst_w;
+    d.inv_hw = 1.0f / (float)d.dst_hw;
+    d.inv_w = 1.0f / (float)d.dst_w;
     d.m_begin = m;
     if (d.src_h > 32767 || d.src_w > 32767 || d.src_h < 0 || d.src_w < 0) return false;
+    if ((long long)m + (long long)g->batch * d.dst_hw >= (1ll << 24)) return false;   // fast_div range
     m += g->batch * d.dst_hw;
   }
   *M_out = m;
@@ -1581,6 +1726,62 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);
   else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
   return true;
+}
+
+template <int CG, int NB, int MODE>
+void launch_smallc(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
+  constexpr int BP = 256, BC = 16 * NB;
+  constexpr int NKC = (9 * 8 * CG + 31) / 32, WG = NKC * 4 + 1;
+  ConvParams q = p;
+  q.n_ctiles = (p.N + BC - 1) / BC;
+  const int ptiles = (p.M + BP - 1) / BP;
+  q.n_ptiles = ptiles;
+  // patch rows [m0 - halo, m0 + BP + halo) + the zero row, padded to whole 1-KB LDS-DMA bursts
+  const int patch_bytes = ((BP + 2 * halo + 1) * 16 * CG + 1023) / 1024 * 1024;
+  const size_t wbytes = (size_t)(BC * WG + 63) / 64 * 1024;
+  size_t lds = (size_t)patch_bytes + wbytes + 256 * sizeof(int);
+  const size_t epi = (size_t)2 * BC * sizeof(float) + 4096;      // statistics scratch of the epilogue
+  if (lds < epi) lds = epi;
+  auto kern = conv3x3_smallc_kernel<CG, NB, MODE>;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q, halo, total_rows, patch_bytes, (int)wbytes);
+}
+
+// 3x3/s1/p1 layers with 8, 16 or 32 gather-source channels on maps up to 256 wide, both sides packed identically.
+template <int MODE>
+bool dispatch_smallc(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
+  static const int force = []() {
+    const char* e = getenv("KD6D_CONV_SMALLC");   // tuning aid: 0 = off
+    return e ? atoi(e) : -1;
+  }();
+  if (force == 0) return false;
+  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C != 8 && p.C != 16 && p.C != 32) || (p.N & 3)) return false;
+  if (p.stats && p.stats_groups > 0) return false;      // the group-statistics table wants the big staging buffers
+  // one burst per workgroup, no pipeline: pays once >= 2 workgroups per CU overlap each other (measured: the
+  // 64x64-pixel layers and below are faster on the pipelined kernels)
+  if (force < 0 && p.M < (1 << 17)) return false;
+  int wmax = 0, rows = 0;
+  for (int s = 0; s < g->nseg; ++s) {
+    const kd6d_seg& q = g->seg[s];
+    if (q.in_row0 != q.out_row0 || q.in_row0 != rows) return false;
+    if (q.in_w > wmax) wmax = q.in_w;
+    rows += g->batch * q.in_h * q.in_w;
+  }
+  if (wmax > 256) return false;
+  const int halo = wmax + 1;
+  const int nb = p.N <= 16 ? 1 : (p.N <= 32 ? 2 : (p.N <= 64 ? 4 : 8));
+#define KD6D_SMALLC_CASE(CG_, NB_) \
+  if (p.C == 8 * CG_ && nb == NB_) { launch_smallc<CG_, NB_, MODE>(p, halo, rows, st); return true; }
+  KD6D_SMALLC_CASE(1, 1) KD6D_SMALLC_CASE(1, 2) KD6D_SMALLC_CASE(1, 4) KD6D_SMALLC_CASE(1, 8)
+  KD6D_SMALLC_CASE(2, 1) KD6D_SMALLC_CASE(2, 2) KD6D_SMALLC_CASE(2, 4) KD6D_SMALLC_CASE(2, 8)
+  KD6D_SMALLC_CASE(4, 1) KD6D_SMALLC_CASE(4, 2) KD6D_SMALLC_CASE(4, 4) KD6D_SMALLC_CASE(4, 8)
+#undef KD6D_SMALLC_CASE
+  return false;
 }
 
 template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE>
@@ -1794,11 +1995,10 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
                    g->cout, stats_groups);
     p.stats = stats; p.stats_groups = stats_groups;
     if (stats_groups > 0) p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
-    for (int s = 0; s < g->nseg; ++s) p.seg_inv_hw[s] = 1.0f / (float)(p.seg[s].dst_hw);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    if (!dispatch_halo<MODE_FWD>(p, g, st) &&
+    if (!dispatch_smallc<MODE_FWD>(p, g, st) && !dispatch_halo<MODE_FWD>(p, g, st) &&
         !dispatch_splitk<MODE_FWD>(p, reinterpret_cast<float*>(workspace), (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), st) &&
         !dispatch_glds<MODE_FWD>(p, st))
       dispatch_igemm<bf16_t, MODE_FWD>(p, st);
@@ -1827,7 +2027,8 @@ extern "C" int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void*
   p.act = KD6D_ACT_NONE; p.out_f32 = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    if (!dispatch_halo<MODE_DGRAD>(p, g, st) && !dispatch_glds<MODE_DGRAD>(p, st)) dispatch_igemm<bf16_t, MODE_DGRAD>(p, st);
+    if (!dispatch_smallc<MODE_DGRAD>(p, g, st) && !dispatch_halo<MODE_DGRAD>(p, g, st) && !dispatch_glds<MODE_DGRAD>(p, st))
+      dispatch_igemm<bf16_t, MODE_DGRAD>(p, st);
   } else {
     dispatch_igemm<float, MODE_DGRAD>(p, st);
   }

@@ -45,6 +45,13 @@ CONV_CASES = [
     (2, 128, 256, 3, 1, [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]),
     (1, 64, 240, 3, 1, [(64, 64)]),
     (3, 192, 64, 3, 1, [(5, 7), (3, 2)]),
+    # 3x3/s1 with C in {8, 16, 32}: the resident-patch kernel (wide maps, K padding, N tails, two channel tiles)
+    (2, 8, 8, 3, 1, [(256, 256)]),
+    (2, 32, 64, 3, 1, [(256, 256)]),
+    (1, 16, 128, 3, 1, [(64, 64)]),
+    (2, 32, 64, 3, 1, [(128, 128)]),
+    (2, 32, 256, 3, 1, [(16, 16), (8, 8)]),
+    (3, 16, 24, 3, 1, [(9, 7)]),
 ]
 
 
@@ -240,6 +247,22 @@ def test_conv_fwd_fused_statistics(gpu_device, dtype, case):
     torch.testing.assert_close(st, ref, rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0))
     for x, gl in zip(xs, got_y):              # and the output itself is unchanged by the statistics pass
         torch.testing.assert_close(gl, F.conv2d(x, w, bias, stride=stride, padding=pad), **_tol(dtype, stored=False))
+
+
+def test_conv_resident_patch_kernel_on_every_small_c_case(gpu_device):
+    """The resident-patch kernel (C in {8,16,32}) is dispatched from 2^17 pixels up; KD6D_CONV_SMALLC=1 lifts the
+    size rule so the small / ragged CONV_CASES (multi-level, N tails, two channel tiles) run through it as well.
+    The switch is read once per process, hence the child interpreter."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("KD6D_CONV_SMALLC") == "1":
+        pytest.skip("already the forced run")
+    env = dict(os.environ, KD6D_CONV_SMALLC="1")
+    sel = "test_conv_fwd_plain or test_conv_dgrad or test_conv_fwd_fused_statistics"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_pack_dgrad_weights(gpu_device):
