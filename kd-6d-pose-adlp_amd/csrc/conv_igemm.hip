@@ -1209,18 +1209,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // reuse the row decoder through a ConvParams-shaped view
   auto decode = [&](int m, int& y, int& xq, int& sh, int& sw, int& sbase) {
     int mb = 0, hw = 1, dw = 1, s0 = 0;
+    float ihw = 1.f, iw = 1.f;
     sh = 0; sw = 0;
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
       if (s < p.nseg && m >= p.seg[s].m_begin) {
         mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; dw = p.seg[s].dst_w;
         sh = p.seg[s].src_h; sw = p.seg[s].src_w; s0 = p.seg[s].src_row0;
+        ihw = p.seg[s].inv_hw; iw = p.seg[s].inv_w;
       }
     }
     const int local = m - mb;
-    const int b = local / hw;
+    const int b = fast_div(local, hw, ihw);
     const int rem = local - b * hw;
-    y = rem / dw;
+    y = fast_div(rem, dw, iw);
     xq = rem - y * dw;
     sbase = s0 + b * sh * sw;
   };
@@ -1409,17 +1411,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
     const bool mv = m < m_hi;
     // pixel decode (level, image, y, x) once per k-step
     int mb = 0, hw = 1, dw = 1, sh = 0, sw = 0, s0 = 0;
+    float ihw = 1.f, iw = 1.f;
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
       if (s < p.nseg && m >= p.seg[s].m_begin) {
         mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; dw = p.seg[s].dst_w;
         sh = p.seg[s].src_h; sw = p.seg[s].src_w; s0 = p.seg[s].src_row0;
+        ihw = p.seg[s].inv_hw; iw = p.seg[s].inv_w;
       }
     }
     const int local = m - mb;
-    const int b = local / hw;
+    const int b = fast_div(local, hw, ihw);
     const int rem = local - b * hw;
-    const int y = rem / dw;
+    const int y = fast_div(rem, dw, iw);
     const int xq = rem - y * dw;
     const int sbase = s0 + b * sh * sw;
     const int by = y * p.stride - p.pad, bx = xq * p.stride - p.pad;
@@ -1698,7 +1702,9 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
     return e ? atoi(e) : -1;
   }();
   if (force == 0) return false;
-  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C & 63) || p.N < 64) return false;
+  static const int narrow = []() { const char* e = getenv("KD6D_CONV_HALO_NARROW"); return e ? atoi(e) : 1; }();
+  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C & 63) || (p.N & 3)) return false;
+  if (p.N < 64 && (!narrow || p.N > 32)) return false;
   int wmax = 0, rows = 0;
   for (int s = 0; s < g->nseg; ++s) {
     const kd6d_seg& q = g->seg[s];
@@ -1716,7 +1722,8 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   // below that the layer goes to split-K / the generic kernels.
   const int pt128 = (p.M + 127) / 128;
   int pick = 0;
-  if (((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
+  if (p.N <= 32) pick = 5;             // few result channels (cls logits, dgrad into the narrow student stages): 128 x 32
+  else if (((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
   else if (pt128 * ((p.N + 127) / 128) >= 160) pick = 3;
   else if (pt128 * ((p.N + 63) / 64) >= 64) pick = 4;
   if (force > 0) pick = force;
@@ -1724,6 +1731,7 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   if (pick == 1) launch_halo<256, 128, 4, 2, MODE>(p, halo, rows, st);
   else if (pick == 3) launch_halo<128, 128, 4, 2, MODE>(p, halo, rows, st);      // 8 waves on the 128x128 tile
   else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);
+  else if (pick == 5) launch_halo<128, 32, 4, 1, MODE>(p, halo, rows, st);
   else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
   return true;
 }

@@ -45,6 +45,8 @@ CONV_CASES = [
     (2, 128, 256, 3, 1, [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]),
     (1, 64, 240, 3, 1, [(64, 64)]),
     (3, 192, 64, 3, 1, [(5, 7), (3, 2)]),
+    (2, 16, 64, 3, 1, [(32, 32)]),                     # dgrad: 64 -> 16 channels, the 128x32 halo tile
+    (2, 256, 24, 3, 1, [(16, 16), (8, 8)]),            # fwd: narrow result with an N tail
     # 3x3/s1 with C in {8, 16, 32}: the resident-patch kernel (wide maps, K padding, N tails, two channel tiles)
     (2, 8, 8, 3, 1, [(256, 256)]),
     (2, 32, 64, 3, 1, [(256, 256)]),
