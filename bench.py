@@ -179,6 +179,14 @@ def main():
         elapsed = float(t.item())
     losses = {k: float(v) for k, v in ld.items()}
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
+    # host cost of issuing one step onto an idle GPU (in the timed loop the host mostly waits for queue space)
+    t_issue = []
+    for j in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(args.warmup + args.steps + j)
+        t_issue.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
 
     # ---- roofline leg: per-launch HIP-event timing of every conv launch, in instrumented steps that
     # every rank runs (the step contains the gradient all-reduce) but only rank 0 records ----
@@ -237,6 +245,7 @@ def main():
                               "student steps on single batches" % (gstep.G, gstep.G * B))),
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
                "losses_last_step": losses, "finite": finite, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+               "host_issue_ms_idle_gpu": min(t_issue) * 1e3,
                "roofline": roof}
         # ---- CPU baseline leg (oracle = port of the reference step), rank 0, N=1 only ----
         if world == 1 and not args.no_cpu_baseline:

@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         n = r["Kernel_Name"]
         if "conv" not in n or "pack_dgrad" in n:
             continue
-        key = "halo" if "halo" in n else "glds" if "glds" in n else "wgrad" if "wgrad" in n else "splitk_finalize" if "finalize" in n else "igemm"
+        key = "smallc" if "smallc" in n else "halo" if "halo" in n else "glds" if "glds" in n else "wgrad" if "wgrad" in n else "splitk_finalize" if "finalize" in n else "igemm"
         per[key][0] += 1
         per[key][1] += float(r["Counter_Value"])
     out[c] = {k: {"launches": v[0], "counter_sum": v[1]} for k, v in per.items()}
