@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 3
+#define KD6D_ABI_VERSION 4
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -126,7 +126,10 @@ int kd6d_device_cu_count(void);
  * kd6d_colstats (per-channel sum / sum of squares, fp32 atomics into pre-zeroed buffers), then
  * kd6d_bn_train_fwd normalises, updates running stats (momentum 0.1, unbiased var) and saves
  * mean / invstd for the backward pair.  x_f32 != 0: the pre-normalisation tensor x is fp32 while
- * activations/gradients are `dtype` (keeps (x - mean) free of bf16 cancellation error). */
+ * activations/gradients are `dtype` (keeps (x - mean) free of bf16 cancellation error).
+ * Backward pair: sum_dy / sum_dy_xhat are `replicas` (1..64) rows of C floats each, pre-zeroed; the
+ * reduction's workgroups spread their per-channel atomics over the rows (same-address atomics retire
+ * serially, ~27 ns each, and this kernel needs hundreds of workgroups), the apply kernel sums the rows. */
 int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum, float* sumsq, void* stream);
 int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows, int C, const float* sum,
                       const float* sumsq, const float* gamma, const float* beta, float eps, float momentum,
@@ -134,11 +137,11 @@ int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows
                       int act, void* stream);
 int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, const void* dz, int64_t rows, int C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                             int act, float* sum_dy, float* sum_dy_xhat, void* stream);
+                             int act, float* sum_dy, float* sum_dy_xhat, int replicas, void* stream);
 int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
                             const float* mean, const float* invstd, const float* gamma, const float* beta,
                             int act, const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
-                            float* dbeta, void* stream);
+                            float* dbeta, int replicas, void* stream);
 
 /* GroupNorm(groups)+ReLU of the PoseHead towers (models/model.py:395-417) over a multi-level
  * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 floats per

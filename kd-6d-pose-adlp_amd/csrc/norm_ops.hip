@@ -23,9 +23,11 @@ __device__ __forceinline__ float row_ror_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + O, 0xF, 0xF, true));
 }
 
+// out[a]: `replicas` rows of C floats; this workgroup adds into row blockIdx.x % replicas (the rows are summed
+// by the consumer), so an address sees 1/replicas of the serially retired atomics.
 template <int NACC, int EG>
 __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int C, int cg,
-                                                    float* const* out) {
+                                                    float* const* out, int replicas = 1) {
   extern __shared__ float red[];  // NACC * C floats
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) red[i] = 0.f;
   __syncthreads();
@@ -54,9 +56,10 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
       for (int e = 0; e < EG; ++e) atomicAdd(&red[a * C + cg * EG + e], acc[a][e]);
   }
   __syncthreads();
+  const int roff = replicas > 1 ? (int)(blockIdx.x % replicas) * C : 0;
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
     const int a = i / C, c = i - a * C;
-    if (out[a]) atomicAdd(out[a] + c, red[i]);
+    if (out[a]) atomicAdd(out[a] + roff + c, red[i]);
   }
 }
 
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, long long ngran, int C,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy,
-    float* sum_dy_xhat) {
+    float* sum_dy_xhat, int replicas) {
   constexpr int EG = Granule<T>::N;
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     }
   }
   float* outs[2] = {sum_dy, sum_dy_xhat};
-  block_channel_flush<2, EG>(acc, C, cg, outs);
+  block_channel_flush<2, EG>(acc, C, cg, outs, replicas);
 }
 
 template <typename T, typename TX>
@@ -201,22 +204,34 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* dgamma,
-    float* dbeta) {
+    float* dbeta, int replicas) {
   constexpr int EG = Granule<T>::N;
+  extern __shared__ float tot[];             // 2 * C: replica rows of the two reductions, summed once per workgroup
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
+    const float* __restrict__ src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
+    float t = src[0];
+    for (int r = 1; r < replicas; ++r) t += src[(size_t)r * C];
+    tot[i] = t;
+  }
   float m[EG], is[EG], ga[EG], be[EG], k1[EG], k2[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
-    k1[e] = sum_dy[c] * inv_rows;
-    k2[e] = sum_dy_xhat[c] * inv_rows;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    k1[e] = tot[c] * inv_rows;
+    k2[e] = tot[C + c] * inv_rows;
   }
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += kThreads) {
-      if (dgamma) dgamma[c] += sum_dy_xhat[c];
-      if (dbeta) dbeta[c] += sum_dy[c];
+      if (dgamma) dgamma[c] += tot[C + c];
+      if (dbeta) dbeta[c] += tot[c];
     }
   }
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
@@ -246,7 +261,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
 // so a 32x32 level is reduced by 16 workgroups instead of one); consumers derive
 // mean = s/n, rstd = rsqrt(max(q/n - mean^2, 0) + eps) with n = H*W*C/G.
 // ---------------------------------------------------------------------------
-constexpr int kGnRows = 64;   // rows of one (level, sample) handled by a reduction workgroup
+// rows of one (level, sample) handled by a reduction workgroup (GnGeom::chunk_rows)
+int gn_chunk_rows() { static const int v = []() { const char* e = getenv("KD6D_GN_ROWS"); return e ? atoi(e) : 128; }(); return v; }
 
 struct GnGeom {
   int nseg, batch, C, G;
@@ -255,6 +271,7 @@ struct GnGeom {
   int nblk;                   // reduction workgroups in all
   int blk0[KD6D_MAX_SEG];     // first reduction workgroup of the level
   int cps[KD6D_MAX_SEG];      // reduction workgroups (row chunks) per sample
+  int chunk_rows;
 };
 
 // reduction workgroup -> (seg, b, first row, row count)
@@ -267,8 +284,8 @@ __device__ __forceinline__ void gn_chunk(const GnGeom& gm, int blk, int& seg, in
   const int local = blk - b0;
   b = local / cps;
   const int chunk = local - b * cps;
-  const int lo = chunk * kGnRows;
-  r_cnt = min(kGnRows, hw - lo);
+  const int lo = chunk * gm.chunk_rows;
+  r_cnt = min(gm.chunk_rows, hw - lo);
   r_begin = row0 + b * hw + lo;
 }
 
@@ -697,6 +714,13 @@ __global__ __launch_bounds__(kThreads) void image_to_nhwc_kernel(const float* __
   }
 }
 
+// Every workgroup of a per-channel reduction ends with one atomic per channel, and same-address atomics
+// retire serially, ~27 ns each (measured: time grows linearly with the workgroup count, 512 -> 2048 = 18 -> 55 us
+// on a 17-MB tensor).  colstats' plain load loop tolerates long per-thread walks, so it is capped at 128
+// workgroups; the BatchNorm backward reduction is latency-bound per thread (8 granules at most) and keeps 512.
+constexpr int kColstatsCap = 128;
+constexpr int kBnBwdReduceCap = 512;
+
 int grid_for(long long work_items) {
   long long b = (work_items + kThreads - 1) / kThreads;
   if (b > 2048) b = 2048;
@@ -716,6 +740,7 @@ int check_channels(int dtype, int C, const char* who) {
 bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom* gm) {
   if (nseg < 1 || nseg > KD6D_MAX_SEG || batch < 1 || G < 1 || G > 64 || C % G) return false;
   gm->nseg = nseg; gm->batch = batch; gm->C = C; gm->G = G;
+  gm->chunk_rows = gn_chunk_rows();
   int row = 0, blk = 0;
   for (int s = 0; s < KD6D_MAX_SEG; ++s) {
     gm->row0[s] = row;
@@ -725,7 +750,7 @@ bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom*
     if (s < nseg) {
       if (level_hw[s] <= 0) return false;
       row += batch * level_hw[s];
-      gm->cps[s] = (level_hw[s] + kGnRows - 1) / kGnRows;
+      gm->cps[s] = (level_hw[s] + gm->chunk_rows - 1) / gm->chunk_rows;
       blk += batch * gm->cps[s];
     }
   }
@@ -754,7 +779,7 @@ extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, floa
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int rpp = kThreads / (C / eg);
   long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
-  if (nb > 512) nb = 512;
+  if (nb > kColstatsCap) nb = kColstatsCap;
   if (nb < 1) nb = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
   DISPATCH_T(dtype,
@@ -798,9 +823,10 @@ extern "C" int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, i
 extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, const void* dz, int64_t rows,
                                         int C, const float* mean, const float* invstd, const float* gamma,
                                         const float* beta, int act, float* sum_dy, float* sum_dy_xhat,
-                                        void* stream) {
+                                        int replicas, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_reduce");
   if (rc) return rc;
+  KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_train_bwd_reduce: replicas=%d outside [1,64]", replicas);
   KD6D_CHECK_ARG(x && dz && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
                  "kd6d_bn_train_bwd_reduce: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -809,13 +835,13 @@ extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, con
   // every workgroup ends with one global atomic per channel and same-address atomics retire serially
   // (~25 ns each): 2 workgroups per CU keep the loads in flight without a 1000-deep atomic queue
   long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
-  if (nb > 512) nb = 512;
+  if (nb > kBnBwdReduceCap) nb = kBnBwdReduceCap;
   if (nb < 1) nb = 1;
   const size_t lds = (size_t)2 * C * sizeof(float);
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads), lds, st,
                                    (const TX_*)x, (const T_*)dz, ngran, C, mean, invstd, gamma, beta, act, sum_dy,
-                                   sum_dy_xhat));
+                                   sum_dy_xhat, replicas));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_reduce");
   return KD6D_OK;
 }
@@ -824,9 +850,10 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, cons
                                        int64_t rows, int C, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, int act,
                                        const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
-                                       float* dbeta, void* stream) {
+                                       float* dbeta, int replicas, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_apply");
   if (rc) return rc;
+  KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_train_bwd_apply: replicas=%d outside [1,64]", replicas);
   KD6D_CHECK_ARG(x && dz && dx && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
                  "kd6d_bn_train_bwd_apply: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -835,9 +862,10 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, cons
   const int nb = grid_for((ngran + 3) / 4);
   const float inv_rows = 1.f / (float)rows;
   DISPATCH_TTX(dtype, x_f32,
-               hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st,
+               hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads),
+                                   (size_t)2 * C * sizeof(float), st,
                                    (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, C, inv_rows, mean, invstd, gamma,
-                                   beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta));
+                                   beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta, replicas));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_apply");
   return KD6D_OK;
 }

@@ -226,6 +226,11 @@ class ConvBlock:
     """conv(no bias) + BN + LeakyReLU(0.1)  (backbone/common.py:250-324)."""
     FUSE_STATS_MAX_ROWS = 1 << 15      # up to 256 workgroups adding into one channel; beyond that a separate pass wins
 
+    @staticmethod
+    def bwd_replicas(rows):
+        """Replica rows of the backward reduction's accumulators (kd6d.h): from 64 workgroups up."""
+        return 8 if rows >= (1 << 14) else 1
+
     def __init__(self, net, name, cin, cout, k, stride=1):
         self.net, self.name = net, name
         self.conv = Conv(net, name + ".conv", cin, cout, k, stride, bias=False)
@@ -241,9 +246,9 @@ class ConvBlock:
         net, st = self.net, self.net.store
         # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
         c = self.conv.cout_p
-        s = net.scratch(self.name, 6 * c)
-        ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
         geom = self.conv.geom(batch, levels)
+        s = net.scratch(self.name, (4 + 2 * self.bwd_replicas(geom.rows_out)) * c)
+        ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
         # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
         # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
         fused = geom.rows_out <= self.FUSE_STATS_MAX_ROWS
@@ -262,11 +267,14 @@ class ConvBlock:
         _, x, raw, batch, levels = rec
         net, st = self.net, self.net.store
         c = self.conv.cout_p
-        s = net.scratch(self.name, 6 * c)
-        mean, invstd, w1, w2 = s[2 * c:3 * c], s[3 * c:4 * c], s[4 * c:5 * c], s[5 * c:6 * c]
+        R = self.bwd_replicas(raw.shape[0])
+        s = net.scratch(self.name, (4 + 2 * R) * c)
+        mean, invstd = s[2 * c:3 * c], s[3 * c:4 * c]
+        w1, w2 = s[4 * c:(4 + R) * c], s[(4 + R) * c:(4 + 2 * R) * c]
         draw = net.buf(self.name + ".draw", raw.shape, net.dtype)
         ops.bn_train_bwd(raw, dz, draw, mean, invstd, st.storage(self.bn.gamma), st.storage(self.bn.beta),
-                         ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"), st.storage(self.bn.beta, "grads"))
+                         ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"), st.storage(self.bn.beta, "grads"),
+                         replicas=R)
         return self.conv.bwd(x, draw, batch, levels, need_dx=need_dx, dx=dx, accumulate=accumulate)
 
 

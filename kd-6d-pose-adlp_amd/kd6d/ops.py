@@ -175,16 +175,18 @@ def bn_train_fwd(x, y, sum_, sumsq, gamma, beta, eps, momentum, running_mean, ru
     return y
 
 
-def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta):
+def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta, replicas=1):
+    """ws_sum_dy / ws_sum_dy_xhat: `replicas` rows of C floats each, pre-zeroed (kd6d.h)."""
     rows, c = x.shape
+    assert ws_sum_dy.numel() >= replicas * c and ws_sum_dy_xhat.numel() >= replicas * c
     code = dt_code(dz.dtype)
     xf = _xf32(x, dz.dtype)
     check(lib.kd6d_bn_train_bwd_reduce(code, xf, _ptr(x), _ptr(dz), rows, c, _ptr(mean), _ptr(invstd),
                                        _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
-                                       _ptr(ws_sum_dy_xhat), _stream()), "kd6d_bn_train_bwd_reduce")
+                                       _ptr(ws_sum_dy_xhat), replicas, _stream()), "kd6d_bn_train_bwd_reduce")
     check(lib.kd6d_bn_train_bwd_apply(code, xf, _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
                                       _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
-                                      _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), _stream()),
+                                      _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), replicas, _stream()),
           "kd6d_bn_train_bwd_apply")
     return dx
 

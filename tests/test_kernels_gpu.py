@@ -321,9 +321,10 @@ def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows):
     mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
     ops.bn_train_fwd(xd, y, s1, s2, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm_d, rv_d, mean, invstd, 1)
     dx = torch.empty_like(dzd)
-    w1 = torch.zeros(C, device=dev); w2 = torch.zeros(C, device=dev)
+    R = 1 if rows < 1000 else 8            # replica rows of the backward accumulators (kd6d.h)
+    w1 = torch.zeros(R * C, device=dev); w2 = torch.zeros(R * C, device=dev)
     dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
-    ops.bn_train_bwd(xd, dzd, dx, mean, invstd, gamma.to(dev), beta.to(dev), 1, w1, w2, dgam, dbet)
+    ops.bn_train_bwd(xd, dzd, dx, mean, invstd, gamma.to(dev), beta.to(dev), 1, w1, w2, dgam, dbet, replicas=R)
     torch.cuda.synchronize()
     tol = _tol(dtype, stored=True)
     torch.testing.assert_close(y.cpu().double(), yr.detach(), **tol)
