@@ -1674,6 +1674,11 @@ void launch_glds(const ConvParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q);
 }
 
+int cached_cu_count() {       // one device per process
+  static const int n = []() { const int c = kd6d_device_cu_count(); return c > 0 ? c : 256; }();
+  return n;
+}
+
 template <int BP, int BC, int WP, int WC, int MODE>
 void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
   constexpr int NW = WP * WC;
@@ -1722,7 +1727,13 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   // below that the layer goes to split-K / the generic kernels.
   const int pt128 = (p.M + 127) / 128;
   int pick = 0;
+  const int ct128 = (p.N + 127) / 128;
+  const int ncu = cached_cu_count();
   if (p.N <= 32) pick = 5;             // few result channels (cls logits, dgrad into the narrow student stages): 128 x 32
+  // 192 x 128 where it turns 256-pixel tiles that leave a third of the CUs idle into one full round (teacher head
+  // towers: 172 tiles of 256 pixels on 256 CUs -> 228 tiles of 192)
+  else if (((p.M + 255) / 256) * ct128 >= 150 && ((p.M + 255) / 256) * ct128 <= (3 * ncu) / 4 &&
+           ((p.M + 191) / 192) * ct128 <= ncu) pick = 6;
   else if (((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
   else if (pt128 * ((p.N + 127) / 128) >= 160) pick = 3;
   else if (pt128 * ((p.N + 63) / 64) >= 64) pick = 4;
@@ -1732,6 +1743,7 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   else if (pick == 3) launch_halo<128, 128, 4, 2, MODE>(p, halo, rows, st);      // 8 waves on the 128x128 tile
   else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);
   else if (pick == 5) launch_halo<128, 32, 4, 1, MODE>(p, halo, rows, st);
+  else if (pick == 6) launch_halo<192, 128, 4, 2, MODE>(p, halo, rows, st);
   else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
   return true;
 }
@@ -1914,11 +1926,6 @@ void launch_wgrad(const WgradParams& p, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, st, q);
-}
-
-int cached_cu_count() {       // one device per process
-  static const int n = []() { const int c = kd6d_device_cu_count(); return c > 0 ? c : 256; }();
-  return n;
 }
 
 template <int BN, int WN, int WJ>

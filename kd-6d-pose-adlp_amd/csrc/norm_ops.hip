@@ -209,29 +209,44 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
   extern __shared__ float tot[];             // 2 * C: replica rows of the two reductions, summed once per workgroup
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
-  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
-    const float* __restrict__ src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
-    float t = src[0];
-    for (int r = 1; r < replicas; ++r) t += src[(size_t)r * C];
-    tot[i] = t;
-  }
   float m[EG], is[EG], ga[EG], be[EG], k1[EG], k2[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
   }
-  __syncthreads();
+  if (replicas > 1) {                        // wave-uniform
+    for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
+      const float* __restrict__ src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
+      float t = src[0];
+      for (int r = 1; r < replicas; ++r) t += src[(size_t)r * C];
+      tot[i] = t;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int e = 0; e < EG; ++e) {
-    const int c = cg * EG + e;
-    k1[e] = tot[c] * inv_rows;
-    k2[e] = tot[C + c] * inv_rows;
-  }
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += kThreads) {
-      if (dgamma) dgamma[c] += tot[C + c];
-      if (dbeta) dbeta[c] += tot[c];
+    for (int e = 0; e < EG; ++e) {
+      const int c = cg * EG + e;
+      k1[e] = tot[c] * inv_rows;
+      k2[e] = tot[C + c] * inv_rows;
+    }
+    if (blockIdx.x == 0) {
+      for (int c = threadIdx.x; c < C; c += kThreads) {
+        if (dgamma) dgamma[c] += tot[C + c];
+        if (dbeta) dbeta[c] += tot[c];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int c = cg * EG + e;
+      k1[e] = sum_dy[c] * inv_rows;
+      k2[e] = sum_dy_xhat[c] * inv_rows;
+    }
+    if (blockIdx.x == 0) {
+      for (int c = threadIdx.x; c < C; c += kThreads) {
+        if (dgamma) dgamma[c] += sum_dy_xhat[c];
+        if (dbeta) dbeta[c] += sum_dy[c];
+      }
     }
   }
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
