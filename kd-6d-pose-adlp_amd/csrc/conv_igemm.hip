@@ -1703,7 +1703,8 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
 template <int MODE>
 bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
   static const int force = []() {
-    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128, 2 = 128x128 (4 waves), 3 = 128x128, 4 = 128x64
+    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128, 2 = 128x128 (4 waves), 3 = 128x128, 4 = 128x64,
+                                                // 5 = 128x32, 6 = 192x128, 9 = 64x64
     return e ? atoi(e) : -1;
   }();
   if (force == 0) return false;
@@ -1723,13 +1724,18 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   // the same 128x128 tile is 25-40 % slower, one wave per SIMD cannot hide the LDS-DMA / fragment latency):
   //   256x128 once it yields >= 150 workgroups (teacher head, stage 2);
   //   128x128 from >= 160 workgroups (teacher stage 3, FPN 32x32 level, student head towers fwd + dgrad);
-  //   128x64  from >= 64 workgroups (teacher stages 4/5, FPN 16x16 level, student FPN) -- ahead of split-K;
+  //   128x64  from >= 64 workgroups (teacher stage 4, student FPN 32x32 level) -- ahead of split-K;
+  //   192x128 / 64x64 / 128x32: the tile-count corner cases below;
   // below that the layer goes to split-K / the generic kernels.
   const int pt128 = (p.M + 127) / 128;
   int pick = 0;
   const int ct128 = (p.N + 127) / 128;
   const int ncu = cached_cu_count();
-  if (p.N <= 32) pick = 5;             // few result channels (cls logits, dgrad into the narrow student stages): 128 x 32
+  const int ct64 = (p.N + 63) / 64;
+  // few result channels (cls logits, dgrad into the narrow student stages): 128 x 32, or 64 x 64 on small maps
+  if (p.N <= 32) pick = pt128 <= ncu / 2 ? 9 : 5;
+  // 128 x 64 tiles would occupy at most half of the CUs: 64 x 64 (FPN 16x16 level, stage 5, student FPN)
+  else if (pt128 * ct64 <= ncu / 2 && ((p.M + 63) / 64) * ct64 >= 64) pick = 9;
   // 192 x 128 where it turns 256-pixel tiles that leave a third of the CUs idle into one full round (teacher head
   // towers: 172 tiles of 256 pixels on 256 CUs -> 228 tiles of 192)
   else if (((p.M + 255) / 256) * ct128 >= 150 && ((p.M + 255) / 256) * ct128 <= (3 * ncu) / 4 &&
@@ -1744,6 +1750,7 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);
   else if (pick == 5) launch_halo<128, 32, 4, 1, MODE>(p, halo, rows, st);
   else if (pick == 6) launch_halo<192, 128, 4, 2, MODE>(p, halo, rows, st);
+  else if (pick == 9) launch_halo<64, 64, 4, 2, MODE>(p, halo, rows, st);
   else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
   return true;
 }
