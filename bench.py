@@ -194,6 +194,9 @@ def main():
     if rank == 0:
         ops.profile_begin()
     for i in range(n_instr):
+        # eager launches cost the host ~15 us each, more than most of these kernels run: park the GPU behind a spin
+        # kernel while the host queues the step, so that the event pairs bracket back-to-back kernels, not launch gaps
+        torch.cuda._sleep(int(2.0e9 * 0.010))
         step(args.warmup + args.steps + i, eager=True)
     rec = ops.profile_end() if rank == 0 else []
 

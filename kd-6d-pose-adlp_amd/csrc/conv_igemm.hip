@@ -1879,6 +1879,10 @@ bool dispatch_glds(const ConvParams& p, hipStream_t st) {
   // K (teacher stages 4/5, FPN top) are bound by that round trip and gain from a deep LDS-DMA ring
   int pick = 0;
   if (nblocks(128, 64) < 384) pick = 3;
+  else if (nblocks(128, 64) <= 640 && p.K >= 1024) pick = 2;       // stride-2 stage-3 entry: 28 -> 25 us
+  // k-steps that straddle taps (source channels not a multiple of 64) pay a tap decode per step here; on the
+  // large maps (dgrad of the student's cls / pose heads) the register-staged kernel is 15-25 % faster
+  if (pick == 3 && (p.C & 63) && M > 16384) pick = 0;
   if (force > 0) pick = force;
   if (pick == 0) return false;
   if (pick == 1) launch_glds<128, 128, 2, 2, MODE, 3>(p, st);
