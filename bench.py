@@ -57,6 +57,9 @@ def parse():
                         "(1 = once per batch); the student always steps on single batches of --batch images")
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--layer-table", type=str, default="", help="write the per-launch conv table (instrumented steps) here")
+    p.add_argument("--timeline", action="store_true",
+                   help="analysis aid: capture device timestamp markers into the graph and print the phase boundaries of the "
+                        "last replayed step to stderr (adds ~15 one-thread launches per step)")
     return p.parse_args()
 
 
@@ -131,6 +134,8 @@ def main():
         gstep = GroupedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=args.teacher_group)
     else:
         gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
+    if args.timeline and gstep is not None:
+        ops.marks_begin(dev)                     # before the capture: the markers become graph nodes
     n_prime = 0
     if gstep is not None and gstep.pipeline:
         # priming calls (teacher only, no student step yet): 1 for the per-batch pipeline, G for the grouped one
@@ -179,6 +184,12 @@ def main():
         elapsed = float(t.item())
     losses = {k: float(v) for k, v in ld.items()}
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
+    if args.timeline and gstep is not None and rank == 0:
+        buf, slots = ops.marks_end()
+        t = buf.cpu().tolist()
+        t0 = t[slots["step.start"]]
+        for name, idx in sorted(slots.items(), key=lambda kv: t[kv[1]]):
+            print("timeline %-28s %9.1f us" % (name, (t[idx] - t0) * 0.01), file=sys.stderr)
     # host cost of issuing one step onto an idle GPU (in the timed loop the host mostly waits for queue space)
     t_issue = []
     for j in range(3):

@@ -121,6 +121,10 @@ typedef struct kd6d_levels {
 
 int kd6d_device_cu_count(void);
 
+/* Timing aid: stores the device's 100-MHz wall clock into *slot when the launch executes on `stream`
+ * (phase boundaries inside a replayed hipGraph; tools/step_timeline.py). */
+int kd6d_mark(unsigned long long* slot, void* stream);
+
 /* ---- normalisation / pooling (HBM-bound, 16-B granules) ------------------------------------
  * BatchNorm2d(train)+LeakyReLU of ConvBlock (backbone/common.py:316-324): batch statistics by
  * kd6d_colstats (per-channel sum / sum of squares, fp32 atomics into pre-zeroed buffers), then

@@ -24,3 +24,17 @@ extern "C" int kd6d_device_cu_count(void) {
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
   return n;
 }
+
+// Device timestamp marker: one lane stores the constant-rate (100 MHz) wall clock at the moment the launch runs.
+// Lets a caller read phase boundaries of a replayed hipGraph whose streams really run concurrently (under
+// rocprofv3 a graph replays one kernel at a time).
+namespace {
+__global__ void mark_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}
+
+extern "C" int kd6d_mark(unsigned long long* slot, void* stream) {
+  KD6D_CHECK_ARG(slot != nullptr, "kd6d_mark: null slot");
+  hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), slot);
+  KD6D_CHECK_LAUNCH("kd6d_mark");
+  return KD6D_OK;
+}

@@ -52,6 +52,7 @@ _D = ctypes.c_double
 SIGNATURES = {
     "kd6d_abi_version": [],
     "kd6d_device_cu_count": [],
+    "kd6d_mark": [_P, _P],
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],

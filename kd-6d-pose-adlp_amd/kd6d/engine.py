@@ -551,6 +551,7 @@ class PoseNet:
             self.scratch_buf[:max(self._scratch_size, 8)].zero_()
         x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=self.buf("input", (B * H * W, 8)))
         feats = self._backbone53(x, B, [(H, W)]) if self.arch == "darknet53" else self._backbone_tiny(x, B, [(H, W)])
+        ops.mark("%s.fwd.backbone.end" % ("teacher" if not self.training else "student"))
         oc = self.out_channel
         idxs = sorted(self.inner.keys())
         top = idxs[-1]
@@ -588,6 +589,7 @@ class PoseNet:
         p6r = ops.eltwise(ops.ELT_RELU, p6, None, self.buf("p6_relu", p6.shape))
         self.p7.fwd(p6r, B, [h6], out=slot(len(idxs) + 1))
         self.p6_ctx = (ftop, lvtop, p6, p6r, h6)
+        ops.mark("%s.fwd.fpn.end" % ("teacher" if not self.training else "student"))
         # ---- head over all levels at once ----
         self.head_ctx = {}
         outs = {}
@@ -630,6 +632,7 @@ class PoseNet:
                     conv.bwd(x_in, draw, B, lv_all, dx=d_head_in, accumulate=not first)
             first = False
         row0 = self.level_row0
+        ops.mark("student.bwd.head.end")
 
         def dslot(li):
             h, w = lv_all[li]
@@ -661,6 +664,7 @@ class PoseNet:
             else:
                 dfeat[i] = self.inner[i].bwd(f, d_inner, B, lv, dx=self.buf("dfeat%d" % i, f.shape))
             d_inner_up = (d_inner, h, w)
+        ops.mark("student.bwd.fpn.end")
         # ---- backbone (tiny): walk the tape in reverse ----
         # feats index -> gradient arriving from the FPN; out4 = index 3 (after stage 5), out3 = index 2
         grad = dfeat[top]
@@ -685,6 +689,7 @@ class PoseNet:
                 grad = blk.bwd(rec, grad, need_dx=need_dx,
                                dx=self.buf(blk.name + ".dx", rec[1].shape) if need_dx else None)
             i_rec -= 1
+        ops.mark("student.bwd.main.end")
         for side in (self.side_streams or ([self.side_stream] if self.side_stream is not None else [])):
             torch.cuda.current_stream().wait_stream(side)
         return None

@@ -71,10 +71,13 @@ class GraphedKDStep:
                 return self.teacher(images, targets=tgt, is_teacher=True, cfg_kd=self.cfg_kd)
             self.teacher_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.teacher_stream):
+                ops.mark("teacher.start")
                 pred = self.teacher(images, targets=tgt, is_teacher=True, cfg_kd=self.cfg_kd)
+                ops.mark("teacher.end")
             return DeferredTeacher(pred, self.teacher_stream)
 
     def _forward_backward(self):
+        ops.mark("step.start")
         self.student.zero_grad()
         if not self.pipeline:
             return self._student_step(self._teacher(self.images, self.tgt))
@@ -82,6 +85,7 @@ class GraphedKDStep:
         losses = self._student_step(self.t_cur)                  # ... the student step on batch k-1
         nxt = nxt.join() if isinstance(nxt, DeferredTeacher) else nxt
         self._advance(nxt)
+        ops.mark("step.end")
         return losses
 
     def _advance(self, pred_nxt):

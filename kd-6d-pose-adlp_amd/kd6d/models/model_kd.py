@@ -187,7 +187,9 @@ class PoseModuleKD(nn.Module):
         B = x.shape[0]
         st = net.store
         st.ensure_grads()
+        ops.mark("student.fwd.start")
         cls, reg = net.forward(x)
+        ops.mark("student.fwd.end")
         tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
         if isinstance(pred_t, kd_losses.DeferredTeacher):      # teacher ran concurrently on another stream
             pred_t = pred_t.join()
@@ -197,6 +199,7 @@ class PoseModuleKD(nn.Module):
         losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher,
                                              keys=getattr(self, "_debug_keys", None),
                                              seg_scale=st.storage(net.scales))
+        ops.mark("student.loss.end")
         self._nbt += 1
         return losses
 
@@ -223,7 +226,9 @@ class PoseModuleKD(nn.Module):
         dreg = net.buf("dreg", (rows, self.net.pose_pred.cout_p))
         dreg.zero_()
         self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.storage(net.scales, "grads"))
+        ops.mark("student.bwd.start")
         net.backward(dcls, dreg)
+        ops.mark("student.bwd.end")
         from ..libs import distributed as D
         if D.get_world_size() > 1 and not getattr(self, "_defer_allreduce", False):
             D.allreduce_mean_(st.grads[:st.n_train])      # GraphedKDStep issues it between its two graphs

@@ -149,6 +149,31 @@ def device_cu_count():
     return n
 
 
+_marks = None          # (int64 tensor, {name: slot}) while a timeline is being recorded (tools/step_timeline.py)
+
+
+def mark(name):
+    """Device timestamp into the slot registered for `name`; no-op unless marks_begin() was called."""
+    if _marks is None:
+        return
+    buf, slots = _marks
+    idx = slots.setdefault(name, len(slots))
+    assert idx < buf.numel(), "too many marks"
+    check(lib.kd6d_mark(ctypes.c_void_p(buf.data_ptr() + 8 * idx), _stream()), "kd6d_mark")
+
+
+def marks_begin(device, n=64):
+    global _marks
+    _marks = (torch.zeros(n, dtype=torch.int64, device=device), {})
+    return _marks
+
+
+def marks_end():
+    global _marks
+    m, _marks = _marks, None
+    return m
+
+
 def pack_dgrad_weights(w_base, wt_base, desc_dev, n_layers, total_blocks):
     check(lib.kd6d_pack_dgrad_weights(dt_code(w_base.dtype), _ptr(w_base), _ptr(wt_base), _ptr(desc_dev),
                                       n_layers, total_blocks, _stream()), "kd6d_pack_dgrad_weights")
