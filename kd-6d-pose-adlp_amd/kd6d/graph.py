@@ -84,6 +84,8 @@ class GraphedKDStep:
         nxt = self._teacher(self.images_nxt, self.tgt_nxt)       # batch k, beside ...
         losses = self._student_step(self.t_cur)                  # ... the student step on batch k-1
         nxt = nxt.join() if isinstance(nxt, DeferredTeacher) else nxt
+        # (running these hand-over copies on the teacher's stream behind the reverse sweep removes the 50 us they
+        # trail the step by, but the extra mid-step dependency costs 120 us: measured, reverted)
         self._advance(nxt)
         ops.mark("step.end")
         return losses
