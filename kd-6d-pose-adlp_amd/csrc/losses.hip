@@ -642,7 +642,7 @@ extern "C" int kd6d_focal_fwd(const float* cls, const int32_t* labels, int rows,
                               float* loss, void* stream) {
   KD6D_CHECK_ARG(cls && labels && loss && rows > 0, "kd6d_focal_fwd: bad arguments");
   int nb = (rows * 15 + kT - 1) / kT;
-  if (nb > 1024) nb = 1024;
+  if (nb > 128) nb = 128;        // one same-address atomic per workgroup, retired serially: 1024 of them were the kernel
   hipLaunchKernelGGL(focal_fwd_kernel, dim3(nb), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), cls, labels,
                      rows, gamma, alpha, loss);
   KD6D_CHECK_LAUNCH("kd6d_focal_fwd");
