@@ -65,14 +65,21 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
     float frame_w, float frame_h, int* __restrict__ t_cnt, float* __restrict__ t_kp,
     float* __restrict__ t_score, int* __restrict__ t_row, float* __restrict__ t_kp_norm,
     float* __restrict__ t_beta) {
-  extern __shared__ float s_cand[];     // cells of the largest level
+  extern __shared__ float s_all[];      // candidate scores of the current class, all levels of this image
   __shared__ float s_v[kT / 64];
   __shared__ int s_i[kT / 64];
   __shared__ unsigned s_mask;
   __shared__ int s_nk[KD6D_MAX_SEG];
   __shared__ int s_total;
+  __shared__ int s_pick_row[64];
+  __shared__ float s_pick_cx[64], s_pick_cy[64], s_pick_sz[64], s_pick_bv[64];
   const int b = blockIdx.x;
-  const float logit_th = logf(th / (1.f - th));
+  int off[KD6D_MAX_SEG];                // first slot of level l in s_all
+  {
+    int o = 0;
+#pragma unroll
+    for (int l = 0; l < KD6D_MAX_SEG; ++l) { off[l] = o; o += l < L.n ? L.h[l] * L.w[l] : 0; }
+  }
 
   // classes with at least one candidate cell
   if (threadIdx.x == 0) s_mask = 0u;
@@ -82,16 +89,20 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
     int h, w, row0; float st, sz;
     level_fields(L, l, h, w, row0, st, sz);
     const int hw = h * w;
-    for (int e = threadIdx.x; e < hw * 15; e += kT) {
-      const int cell = e / 15, c = e - cell * 15;
-      const float x = cls[(size_t)(row0 + b * hw + cell) * 16 + c];
-      if (sigmoidf_(x) > th) mine |= 1u << c;
+    const f32x4_t* rows4 = reinterpret_cast<const f32x4_t*>(cls + (size_t)(row0 + b * hw) * 16);
+#pragma unroll 2
+    for (int cell = threadIdx.x; cell < hw; cell += kT) {      // one 64-B logit row per thread: 4 independent loads
+      f32x4_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = rows4[cell * 4 + u];
+#pragma unroll
+      for (int c = 0; c < 15; ++c)
+        if (sigmoidf_(v[c >> 2][c & 3]) > th) mine |= 1u << c;
     }
   }
   if (mine) atomicOr(&s_mask, mine);
   __syncthreads();
   const unsigned cmask = s_mask;
-  (void)logit_th;
 
   float ai[4];
   inv2x2(bbox_trans + b * 6, ai);
@@ -100,19 +111,36 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
   int emitted = 0;
   for (int c = 0; c < 15 && emitted == 0; ++c) {
     if (!((cmask >> c) & 1u)) continue;
+    // candidate scores of this class for every cell of the image, ONE pass over the logits; the arg-max and
+    // top-n loops below only touch LDS (they used to re-read the logits level by level: 15 dependent global
+    // round trips per image)
+    __syncthreads();
+    for (int l = 0; l < L.n; ++l) {
+      int h, w, row0; float st, sz;
+      level_fields(L, l, h, w, row0, st, sz);
+      const int hw = h * w;
+      int lo = 0;
+#pragma unroll
+      for (int q = 0; q < KD6D_MAX_SEG; ++q) if (q == l) lo = off[q];
+      for (int cell = threadIdx.x; cell < hw; cell += kT) {
+        const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
+        s_all[lo + cell] = p > th ? sqrtf(p) : -1.f;
+      }
+    }
+    __syncthreads();
     // ---- most confident cell per level -> reference box size (postprocess_kd.py:121-141) ----
     float box_conf = 0.f, box_size = 0.f;
     for (int l = 0; l < L.n; ++l) {
       int h, w, row0; float st, sz;
       level_fields(L, l, h, w, row0, st, sz);
       const int hw = h * w;
+      int lo = 0;
+#pragma unroll
+      for (int q = 0; q < KD6D_MAX_SEG; ++q) if (q == l) lo = off[q];
       float bv = -1.f; int bi = 0x7fffffff;
       for (int cell = threadIdx.x; cell < hw; cell += kT) {
-        const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
-        if (p > th) {
-          const float s = sqrtf(p);
-          if (s > bv || (s == bv && cell < bi)) { bv = s; bi = cell; }
-        }
+        const float s = s_all[lo + cell];
+        if (s > 0.f && (s > bv || (s == bv && cell < bi))) { bv = s; bi = cell; }
       }
       block_argmax(bv, bi, s_v, s_i);
       if (bv > 0.f && bv > box_conf) {
@@ -148,12 +176,10 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
       const int hw = h * w;
       const int want = s_nk[l];
       if (want <= 0) continue;
-      // candidate scores of this (class, level) once into LDS; every pick then scans LDS and is struck out
-      for (int cell = threadIdx.x; cell < hw; cell += kT) {
-        const float p = sigmoidf_(cls[(size_t)(row0 + b * hw + cell) * 16 + c]);
-        s_cand[cell] = p > th ? sqrtf(p) : -1.f;
-      }
-      __syncthreads();
+      int lo = 0;
+#pragma unroll
+      for (int q = 0; q < KD6D_MAX_SEG; ++q) if (q == l) lo = off[q];
+      float* const s_cand = s_all + lo;       // every pick scans the level's scores in LDS and is struck out
       for (int t = 0; t < want; ++t) {
         float bv = -1.f; int bi = 0x7fffffff;
         for (int cell = threadIdx.x; cell < hw; cell += kT) {
@@ -162,28 +188,40 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
         }
         block_argmax(bv, bi, s_v, s_i);
         if (bv <= 0.f) break;          // fewer candidates than n_l
-        if (threadIdx.x == 0) s_cand[bi] = -1.f;
-        const int slot = s_total;      // uniform: written only after the barrier below
-        if (slot < cap && threadIdx.x < 8) {
-          const int k = threadIdx.x;
-          const int row = row0 + b * hw + bi;
-          const float* r = reg + (size_t)row * 240 + c * 16;
-          const float cx = (float)(bi % w) * st + st * 0.5f, cy = (float)(bi / w) * st + st * 0.5f;
-          const float px = r[k] * sz + cx - tx, py = r[8 + k] * sz + cy - ty;
-          const size_t o = (size_t)(b * cap + slot);
-          const float fx = ai[0] * px + ai[1] * py, fy = ai[2] * px + ai[3] * py;
-          t_kp[o * 16 + k * 2 + 0] = fx;
-          t_kp[o * 16 + k * 2 + 1] = fy;
-          t_score[o * 8 + k] = bv;
-          // OT inputs (loss_libs.py:8-12 normalisation, kd_loss.py:82 weight = score^2)
-          t_kp_norm[o * 16 + k * 2 + 0] = fx / frame_w;
-          t_kp_norm[o * 16 + k * 2 + 1] = fy / frame_h;
-          t_beta[o * 8 + k] = bv * bv;
-          if (k == 0) t_row[o] = row;
+        if (threadIdx.x == 0) {
+          s_cand[bi] = -1.f;
+          const int slot = s_total;
+          if (slot < cap) {            // decoded after the last pick, all slots in parallel
+            s_pick_row[slot] = row0 + b * hw + bi;
+            s_pick_cx[slot] = (float)(bi % w) * st + st * 0.5f;
+            s_pick_cy[slot] = (float)(bi / w) * st + st * 0.5f;
+            s_pick_sz[slot] = sz;
+            s_pick_bv[slot] = bv;
+          }
+          s_total = slot + 1;
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_total = slot + 1;
-        __syncthreads();
+      }
+    }
+    // ---- decode the picked cells: slot x keypoint in parallel (one global round trip instead of one per pick) ----
+    {
+      const int n = s_total < cap ? s_total : cap;
+      for (int idx = threadIdx.x; idx < n * 8; idx += kT) {
+        const int slot = idx >> 3, k = idx & 7;
+        const int row = s_pick_row[slot];
+        const float sz = s_pick_sz[slot], bv = s_pick_bv[slot];
+        const float* r = reg + (size_t)row * 240 + c * 16;
+        const float px = r[k] * sz + s_pick_cx[slot] - tx, py = r[8 + k] * sz + s_pick_cy[slot] - ty;
+        const size_t o = (size_t)(b * cap + slot);
+        const float fx = ai[0] * px + ai[1] * py, fy = ai[2] * px + ai[3] * py;
+        t_kp[o * 16 + k * 2 + 0] = fx;
+        t_kp[o * 16 + k * 2 + 1] = fy;
+        t_score[o * 8 + k] = bv;
+        // OT inputs (loss_libs.py:8-12 normalisation, kd_loss.py:82 weight = score^2)
+        t_kp_norm[o * 16 + k * 2 + 0] = fx / frame_w;
+        t_kp_norm[o * 16 + k * 2 + 1] = fy / frame_h;
+        t_beta[o * 8 + k] = bv * bv;
+        if (k == 0) t_row[o] = row;
       }
     }
     emitted = s_total;
@@ -204,7 +242,7 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
     const float* __restrict__ bbox_trans, const float* __restrict__ keys, float positive_num,
     float positive_lambda, int cap, int* __restrict__ labels, int* __restrict__ pos_cnt,
     int* __restrict__ pos_row, int* __restrict__ pos_gt) {
-  extern __shared__ float s_cand[];     // cells of the largest level
+  extern __shared__ float s_tab[];      // per cell of this image: mask value at the anchor centre | negated key
   __shared__ float s_v[kT / 64];
   __shared__ int s_i[kT / 64];
   __shared__ int s_has[kMaxGt];
@@ -216,6 +254,27 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
   int G = n_gt[b];
   if (G > kMaxGt) G = kMaxGt;
   const float* m = mask + (size_t)b * mh * mw;
+  int off[KD6D_MAX_SEG], ncell = 0;     // first slot of level l in the tables
+#pragma unroll
+  for (int l = 0; l < KD6D_MAX_SEG; ++l) { off[l] = ncell; ncell += l < L.n ? L.h[l] * L.w[l] : 0; }
+  float* const s_mv = s_tab;            // mask value under the cell's anchor centre (loss.py:193-198)
+  float* const s_nkey = s_tab + ncell;  // -key of the cell, later -inf once struck out / not a candidate
+  // one gather pass over mask + keys; everything below reads these tables (it used to re-gather per level)
+  for (int l = 0; l < L.n; ++l) {
+    int h, w, row0; float st, sz;
+    level_fields(L, l, h, w, row0, st, sz);
+    const int hw = h * w;
+    int lo = 0;
+#pragma unroll
+    for (int q = 0; q < KD6D_MAX_SEG; ++q) if (q == l) lo = off[q];
+    for (int cell = threadIdx.x; cell < hw; cell += kT) {
+      const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
+      const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
+      const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
+      s_mv[lo + cell] = m[iy * mw + ix];
+      s_nkey[lo + cell] = -keys[row0 + b * hw + cell];
+    }
+  }
 
   if (threadIdx.x < kMaxGt) s_has[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_total = 0;
@@ -225,8 +284,22 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
     int has[kMaxGt] = {0, 0, 0, 0};
     const int n4 = ((mh * mw) & 3) == 0 && ((reinterpret_cast<uintptr_t>(m) & 15) == 0) ? (mh * mw) >> 2 : 0;
     const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(m);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4; i += kT) {
+    // one workgroup streams its image's whole mask (256 KB at 256x256): 16 independent 16-B loads in flight per
+    // thread, or the scan is a chain of ~64 memory round trips and half of this kernel's time
+    constexpr int kMlp = 16;
+    int i0 = threadIdx.x;
+    for (; i0 + (kMlp - 1) * kT < n4; i0 += kMlp * kT) {
+      f32x4_t v[kMlp];
+#pragma unroll
+      for (int u = 0; u < kMlp; ++u) v[u] = m4[i0 + u * kT];
+#pragma unroll
+      for (int u = 0; u < kMlp; ++u)
+#pragma unroll
+        for (int g = 0; g < kMaxGt; ++g)
+          has[g] |= (v[u][0] == (float)(g + 1)) | (v[u][1] == (float)(g + 1)) | (v[u][2] == (float)(g + 1)) |
+                    (v[u][3] == (float)(g + 1));
+    }
+    for (int i = i0; i < n4; i += kT) {
       const f32x4_t v = m4[i];
 #pragma unroll
       for (int g = 0; g < kMaxGt; ++g)
@@ -275,11 +348,11 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
     int h, w, row0; float st, sz;
     level_fields(L, l, h, w, row0, st, sz);
     const int hw = h * w;
+    int lo = 0;
+#pragma unroll
+    for (int q = 0; q < KD6D_MAX_SEG; ++q) if (q == l) lo = off[q];
     for (int cell = threadIdx.x; cell < hw; cell += kT) {
-      const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
-      const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
-      const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
-      const float v = m[iy * mw + ix];
+      const float v = s_mv[lo + cell];
       int in_any = 0;
       for (int g = 0; g < G; ++g) in_any |= (v == (float)(g + 1));
       labels[row0 + b * hw + cell] = in_any ? -1 : 0;
@@ -302,18 +375,16 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
       }
       const int want = (int)(positive_num * wl / sum + 0.5f);
       if (want <= 0) continue;
-      // negated keys of the in-mask cells of this (level, instance) once into LDS (arg-max = smallest key)
-      for (int cell = threadIdx.x; cell < hw; cell += kT) {
-        const float cx = (float)(cell % w) * st + st * 0.5f, cy = (float)(cell / w) * st + st * 0.5f;
-        const int ix = (int)fminf(fmaxf(cx, 0.f), (float)(mw - 1));
-        const int iy = (int)fminf(fmaxf(cy, 0.f), (float)(mh - 1));
-        s_cand[cell] = (m[iy * mw + ix] == (float)(g + 1)) ? -keys[row0 + b * hw + cell] : -INFINITY;
-      }
-      __syncthreads();
+      int lo = 0;
+#pragma unroll
+      for (int q = 0; q < KD6D_MAX_SEG; ++q) if (q == l) lo = off[q];
+      const float gid = (float)(g + 1);
+      // arg-max of the negated keys over the in-mask cells of this (level, instance) = smallest key; a picked cell
+      // is struck out of the key table (a cell belongs to one instance, so this cannot hide it from another)
       for (int t = 0; t < want; ++t) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int cell = threadIdx.x; cell < hw; cell += kT) {
-          const float sc = s_cand[cell];
+          const float sc = s_mv[lo + cell] == gid ? s_nkey[lo + cell] : -INFINITY;
           if (sc > bv) { bv = sc; bi = cell; }
         }
         block_argmax(bv, bi, s_v, s_i);
@@ -322,7 +393,7 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
           const int slot = s_total;
           if (slot < 64) { s_sel_row[slot] = row0 + b * hw + bi; s_sel_gt[slot] = g; }
           s_total = slot + 1;
-          s_cand[bi] = -INFINITY;
+          s_nkey[lo + bi] = -INFINITY;
         }
         __syncthreads();
       }
@@ -591,13 +662,10 @@ bool fill_levels(const kd6d_levels* lv, Levels* L) {
 
 }  // namespace
 
-static size_t max_level_cells(const Levels& L) {
-  size_t m = 1;
-  for (int l = 0; l < L.n; ++l) {
-    const size_t c = (size_t)L.h[l] * (size_t)L.w[l];
-    if (c > m) m = c;
-  }
-  return m;
+static size_t total_cells(const Levels& L) {
+  size_t t = 0;
+  for (int l = 0; l < L.n; ++l) t += (size_t)L.h[l] * (size_t)L.w[l];
+  return t > 0 ? t : 1;
 }
 
 extern "C" int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, const float* reg,
@@ -611,7 +679,10 @@ extern "C" int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, 
                      frame_w > 0.f && frame_h > 0.f,
                  "kd6d_teacher_select: bad arguments");
   KD6D_CHECK_ARG(threshold > 0.f && threshold < 1.f, "kd6d_teacher_select: threshold must be in (0,1)");
-  hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch), dim3(kT), max_level_cells(L) * sizeof(float),
+  KD6D_CHECK_ARG(cap <= 64, "kd6d_teacher_select: cap=%d exceeds 64", cap);
+  KD6D_CHECK_ARG(total_cells(L) * sizeof(float) <= 60 * 1024, "kd6d_teacher_select: %zu cells per image exceed the LDS table",
+                 total_cells(L));
+  hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch), dim3(kT), total_cells(L) * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream),
                      cls, reg, L, bbox_trans, threshold, positive_num, positive_lambda, cap, frame_w, frame_h,
                      t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta);
@@ -630,7 +701,9 @@ extern "C" int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int
   KD6D_CHECK_ARG(mask && kp3d && K && class_ids && n_gt && rot && trans && bbox_trans && keys && labels &&
                      pos_cnt && pos_row && pos_gt && cap > 0 && cap <= 64 && mask_h > 0 && mask_w > 0,
                  "kd6d_ssc_assign: bad arguments (cap must be in 1..64)");
-  hipLaunchKernelGGL(ssc_assign_kernel, dim3(L.batch), dim3(kT), max_level_cells(L) * sizeof(float),
+  KD6D_CHECK_ARG(total_cells(L) * 2 * sizeof(float) <= 60 * 1024, "kd6d_ssc_assign: %zu cells per image exceed the LDS tables",
+                 total_cells(L));
+  hipLaunchKernelGGL(ssc_assign_kernel, dim3(L.batch), dim3(kT), total_cells(L) * 2 * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), L,
                      mask, mask_h, mask_w, kp3d, K, class_ids, n_gt, rot, trans, bbox_trans, keys,
                      positive_num, positive_lambda, cap, labels, pos_cnt, pos_row, pos_gt);
