@@ -209,6 +209,16 @@ int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, const float
                         const float* bbox_trans, float threshold, float positive_num, float positive_lambda,
                         int cap, float frame_w, float frame_h, int32_t* t_cnt, float* t_kp, float* t_score,
                         int32_t* t_row, float* t_kp_norm, float* t_beta, void* stream);
+
+/* Pose candidates of the evaluation path (postprocess/postprocess.py:22-121, up to the PnP solver): the
+ * same per-level top-n rule as kd6d_teacher_select, run for EVERY ground-truth slot g < n_gt[b] of image b on
+ * the class class_ids[b*KD6D_MAX_GT + g] (the reference keeps only labels present in target.class_ids).
+ * Output block o = b*KD6D_MAX_GT + g: cnt[o] cells, kp[(o*cap + i)*16 + k*2 + {0,1}] full-frame pixels of
+ * keypoint k, score[(o*cap + i)*8 + k] = sqrt(sigmoid).  The solver (EPnP-RANSAC) runs on the host. */
+int kd6d_pose_candidates(const kd6d_levels* levels, const float* cls, const float* reg,
+                         const float* bbox_trans, const int32_t* class_ids, const int32_t* n_gt,
+                         float threshold, float positive_num, float positive_lambda, int cap,
+                         int32_t* cnt, float* kp, float* score, void* stream);
 int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int mask_h, int mask_w, const float* kp3d,
                     const float* K, const int32_t* class_ids, const int32_t* n_gt, const float* rot,
                     const float* trans, const float* bbox_trans, const float* keys, float positive_num,

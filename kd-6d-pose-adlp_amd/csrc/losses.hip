@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
     const float* __restrict__ bbox_trans, float th, float positive_num, float positive_lambda, int cap,
     float frame_w, float frame_h, int* __restrict__ t_cnt, float* __restrict__ t_kp,
     float* __restrict__ t_score, int* __restrict__ t_row, float* __restrict__ t_kp_norm,
-    float* __restrict__ t_beta) {
+    float* __restrict__ t_beta, const int* __restrict__ class_filter, const int* __restrict__ n_gt) {
   extern __shared__ float s_all[];      // candidate scores of the current class, all levels of this image
   __shared__ float s_v[kT / 64];
   __shared__ int s_i[kT / 64];
@@ -74,6 +74,20 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
   __shared__ int s_pick_row[64];
   __shared__ float s_pick_cx[64], s_pick_cy[64], s_pick_sz[64], s_pick_bv[64];
   const int b = blockIdx.x;
+  // knowledge extraction: one workgroup per image, the first class that emits cells (postprocess_kd.py:86-90);
+  // pose candidates (class_filter != null): workgroup (b, g) handles exactly the class of ground-truth slot g
+  // (postprocess.py:118-121 keeps only labels present in target.class_ids) and writes output block b*MAX_GT + g
+  const int ob = class_filter ? b * KD6D_MAX_GT + (int)blockIdx.y : b;
+  int c_lo = 0, c_hi = 15;
+  if (class_filter) {
+    const int g = blockIdx.y;
+    const int cf = g < n_gt[b] ? class_filter[b * KD6D_MAX_GT + g] : -1;
+    if (cf < 0 || cf >= 15) {
+      if (threadIdx.x == 0) t_cnt[ob] = 0;
+      return;
+    }
+    c_lo = cf; c_hi = cf + 1;
+  }
   int off[KD6D_MAX_SEG];                // first slot of level l in s_all
   {
     int o = 0;
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
   const float tx = bbox_trans[b * 6 + 2], ty = bbox_trans[b * 6 + 5];
 
   int emitted = 0;
-  for (int c = 0; c < 15 && emitted == 0; ++c) {
+  for (int c = c_lo; c < c_hi && emitted == 0; ++c) {
     if (!((cmask >> c) & 1u)) continue;
     // candidate scores of this class for every cell of the image, ONE pass over the logits; the arg-max and
     // top-n loops below only touch LDS (they used to re-read the logits level by level: 15 dependent global
@@ -212,22 +226,23 @@ __global__ __launch_bounds__(kT) void teacher_select_kernel(
         const float sz = s_pick_sz[slot], bv = s_pick_bv[slot];
         const float* r = reg + (size_t)row * 240 + c * 16;
         const float px = r[k] * sz + s_pick_cx[slot] - tx, py = r[8 + k] * sz + s_pick_cy[slot] - ty;
-        const size_t o = (size_t)(b * cap + slot);
+        const size_t o = (size_t)(ob * cap + slot);
         const float fx = ai[0] * px + ai[1] * py, fy = ai[2] * px + ai[3] * py;
         t_kp[o * 16 + k * 2 + 0] = fx;
         t_kp[o * 16 + k * 2 + 1] = fy;
         t_score[o * 8 + k] = bv;
-        // OT inputs (loss_libs.py:8-12 normalisation, kd_loss.py:82 weight = score^2)
-        t_kp_norm[o * 16 + k * 2 + 0] = fx / frame_w;
-        t_kp_norm[o * 16 + k * 2 + 1] = fy / frame_h;
-        t_beta[o * 8 + k] = bv * bv;
-        if (k == 0) t_row[o] = row;
+        if (t_kp_norm) {     // OT inputs (loss_libs.py:8-12 normalisation, kd_loss.py:82 weight = score^2)
+          t_kp_norm[o * 16 + k * 2 + 0] = fx / frame_w;
+          t_kp_norm[o * 16 + k * 2 + 1] = fy / frame_h;
+          t_beta[o * 8 + k] = bv * bv;
+        }
+        if (k == 0 && t_row) t_row[o] = row;
       }
     }
     emitted = s_total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) t_cnt[b] = emitted < cap ? emitted : cap;
+  if (threadIdx.x == 0) t_cnt[ob] = emitted < cap ? emitted : cap;
 }
 
 // ------------------------------------------------------------------------------------
@@ -685,8 +700,27 @@ extern "C" int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, 
   hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch), dim3(kT), total_cells(L) * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream),
                      cls, reg, L, bbox_trans, threshold, positive_num, positive_lambda, cap, frame_w, frame_h,
-                     t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta);
+                     t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta, (const int*)nullptr, (const int*)nullptr);
   KD6D_CHECK_LAUNCH("kd6d_teacher_select");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_pose_candidates(const kd6d_levels* levels, const float* cls, const float* reg,
+                                    const float* bbox_trans, const int32_t* class_ids, const int32_t* n_gt,
+                                    float threshold, float positive_num, float positive_lambda, int cap,
+                                    int32_t* cnt, float* kp, float* score, void* stream) {
+  Levels L;
+  KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_pose_candidates: bad level table");
+  KD6D_CHECK_ARG(cls && reg && bbox_trans && class_ids && n_gt && cnt && kp && score && cap > 0 && cap <= 64,
+                 "kd6d_pose_candidates: bad arguments (cap must be in 1..64)");
+  KD6D_CHECK_ARG(threshold > 0.f && threshold < 1.f, "kd6d_pose_candidates: threshold must be in (0,1)");
+  KD6D_CHECK_ARG(total_cells(L) * sizeof(float) <= 60 * 1024, "kd6d_pose_candidates: %zu cells per image exceed the LDS table",
+                 total_cells(L));
+  hipLaunchKernelGGL(teacher_select_kernel, dim3(L.batch, KD6D_MAX_GT), dim3(kT), total_cells(L) * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream),
+                     cls, reg, L, bbox_trans, threshold, positive_num, positive_lambda, cap, 1.f, 1.f,
+                     cnt, kp, score, (int*)nullptr, (float*)nullptr, (float*)nullptr, class_ids, n_gt);
+  KD6D_CHECK_LAUNCH("kd6d_pose_candidates");
   return KD6D_OK;
 }
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "kd6d_sinkhorn_dense_diameter": [_P, _P, _I, _I, _I, _P, _P, _P],
     "kd6d_sinkhorn_dense_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _D, _P, _I64, _P, _P, _P, _P],
     "kd6d_teacher_select": [_L, _P, _P, _P, _F, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "kd6d_pose_candidates": [_L, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
     "kd6d_ssc_assign": [_L, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "kd6d_focal_fwd": [_P, _P, _I, _F, _F, _P, _P],
     "kd6d_focal_bwd": [_I, _P, _P, _I, _F, _F, _P, _P, _P],

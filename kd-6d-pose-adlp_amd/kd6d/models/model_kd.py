@@ -58,6 +58,9 @@ class PoseModuleKD(nn.Module):
         assert list(cfg["MODEL"]["FEAT_CHANNELS"]) == feat and cfg["MODEL"]["OUT_CHANNEL"] == oc, \
             "cfg FEAT_CHANNELS/OUT_CHANNEL do not match backbone %s" % arch
         self.inference_th = cfg["TEST"]["CONFIDENCE_TH"]
+        from ..postprocess import PostProcessor
+        self.post_processor = PostProcessor(cfg["TEST"]["CONFIDENCE_TH"], cfg["SOLVER"]["POSITIVE_NUM"],
+                                            cfg["SOLVER"]["POSITIVE_LAMBDA"], cfg["DATASETS"].get("SYMMETRY_TYPES", {}))
         self.positive_num = cfg["SOLVER"]["POSITIVE_NUM"]
         self.positive_lambda = cfg["SOLVER"]["POSITIVE_LAMBDA"]
         if cfg["SOLVER"]["POSITIVE_TYPE"] != "SSC" or cfg["SOLVER"]["LOSS_REG_TYPE"] != "3D" or \
@@ -178,8 +181,10 @@ class PoseModuleKD(nn.Module):
             tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
             return kd_losses.teacher_select(cls, reg, net.levels, B, tgt.bbox_trans, self.inference_th,
                                             self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh)
-        raise NotImplementedError("eval-mode pose inference (postprocess/postprocess.py, RANSAC-EPnP) is outside the "
-                                  "KD-step hot path (SURVEY.md 8(f)-2)")
+        # evaluation: candidate cells per ground-truth class on the GPU, PnP-RANSAC on the host (models/model_kd.py:94-95)
+        cls, reg = net.forward(x)
+        tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
+        return self.post_processor(cls, reg, net.levels, B, tgt), {}
 
     def _forward_losses(self, x, targets, pred_t):
         """Student forward + the three loss sums -> fp32[3] device tensor {cls, reg, kd} (unweighted)."""
