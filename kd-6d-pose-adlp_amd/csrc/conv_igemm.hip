@@ -1782,10 +1782,9 @@ void launch_smallc(const ConvParams& p, int halo, int total_rows, hipStream_t st
 // 3x3/s1/p1 layers with 8, 16 or 32 gather-source channels on maps up to 256 wide, both sides packed identically.
 template <int MODE>
 bool dispatch_smallc(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_SMALLC");   // tuning aid: 0 = off
-    return e ? atoi(e) : -1;
-  }();
+  // tuning / test aid, read per call (the parity tests flip it inside one process): 0 = off, 1 = also below 2^17 pixels
+  const char* env = getenv("KD6D_CONV_SMALLC");
+  const int force = env ? atoi(env) : -1;
   if (force == 0) return false;
   if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C != 8 && p.C != 16 && p.C != 32) || (p.N & 3)) return false;
   if (p.stats && p.stats_groups > 0) return false;      // the group-statistics table wants the big staging buffers

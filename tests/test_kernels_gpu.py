@@ -251,20 +251,18 @@ def test_conv_fwd_fused_statistics(gpu_device, dtype, case):
         torch.testing.assert_close(gl, F.conv2d(x, w, bias, stride=stride, padding=pad), **_tol(dtype, stored=False))
 
 
-def test_conv_resident_patch_kernel_on_every_small_c_case(gpu_device):
-    """The resident-patch kernel (C in {8,16,32}) is dispatched from 2^17 pixels up; KD6D_CONV_SMALLC=1 lifts the
-    size rule so the small / ragged CONV_CASES (multi-level, N tails, two channel tiles) run through it as well.
-    The switch is read once per process, hence the child interpreter."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("KD6D_CONV_SMALLC") == "1":
-        pytest.skip("already the forced run")
-    env = dict(os.environ, KD6D_CONV_SMALLC="1")
-    sel = "test_conv_fwd_plain or test_conv_dgrad or test_conv_fwd_fused_statistics"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] == 3 and c[4] == 1])
+def test_conv_resident_patch_kernel_on_every_small_c_case(gpu_device, dtype, case, monkeypatch):
+    """The resident-patch kernel (C in {8,16,32}) is dispatched from 2^17 pixels up; KD6D_CONV_SMALLC=1 (read per
+    call) lifts the size rule so the small / ragged 3x3 CONV_CASES (multi-level, N tails, two channel tiles) run
+    through it as well -- forward, dgrad (where its gather source is narrow) and the fused BatchNorm statistics."""
+    monkeypatch.setenv("KD6D_CONV_SMALLC", "1")
+    test_conv_fwd_plain(gpu_device, dtype, case)
+    test_conv_dgrad(gpu_device, dtype, case)
+    B, Cin, Cout, k, stride, levels = case
+    if Cin in (8, 16, 32) and Cout % 4 == 0:
+        test_conv_fwd_fused_statistics(gpu_device, dtype, (B, Cin, Cout, k, stride, levels, 0))
 
 
 def test_pack_dgrad_weights(gpu_device):
