@@ -1543,6 +1543,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
 }
 
 // ---------------------------------------------------------------------------
+// Weight gradient of the wide, shallow layers (Cin in {8,16,32}, Cout <= 64, 3x3/s1/p1 or 1x1, one level):
+// dW is a few hundred to a few thousand numbers reduced over up to a million pixels.  The general kernel
+// above pads J to 128 columns, decodes a pixel per thread per 64-pixel step and waits one global round trip
+// per step: 16-45 us for 0.02-1.2 GFLOP.  Here a PERSISTENT workgroup walks tiles of R whole image rows:
+//   * the dY rows and the X rows (+1 row above and below) of a tile land in LDS by LDS-DMA, double buffered,
+//     in a ZERO-PADDED 2-D layout -- every image row carries one zero column left and right -- so that tap
+//     (dy,dx) of position q is simply position q + dy*(W+2) + dx and no (pixel, tap) validity mask exists:
+//     the pad positions of dY are zero and contribute nothing;
+//   * the contraction runs over padded positions q; both MFMA operands (8 consecutive q of one channel per
+//     lane) come out of the transposing LDS read, the X operand with the tap's row offset added per lane
+//     (with C = 8 one 16-column block spans two taps, i.e. two offsets inside one read);
+//   * the (n-block, j-block) accumulators are dealt round robin to the 4 waves and live in registers across
+//     ALL tiles of the workgroup; one atomic flush at the end (a few hundred workgroups per address at most).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t tr_read8(const char* base, int row, int pitch, int col_bytes) {
+  typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(base + row * pitch + col_bytes));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(base + (row + 4) * pitch + col_bytes));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int CG, int NB, int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradParams p, int R, int tiles_per_img,
+                                                               int ntiles, int buf_bytes, int prow) {
+  constexpr int C = 8 * CG, J = KS * KS * C, JB = (J + 15) / 16, NBLK = NB * JB, MAXB = (NBLK + 3) / 4;
+  constexpr int DYB = 32 * NB;        // LDS bytes of one dY position (Cout padded to 16 * NB channels)
+  constexpr int PXB = 16 * CG;        // LDS bytes of one X position
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = p.seg[0].dst_w, H = p.seg[0].dst_h;
+  const int Wp = KS == 3 ? W + 2 : W;
+  const float inv_wp = 1.0f / (float)Wp;
+  const int Q = R * Wp, Qpad = (Q + 31) & ~31;
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(p.dy);
+  const char* zero = reinterpret_cast<const char*>(kd6d_zero_page);
+
+  auto issue = [&](int tile, char* b) {
+    const int img = tile / tiles_per_img;
+    const int y0 = (tile - img * tiles_per_img) * R;
+    const size_t ibase = (size_t)img * H * W;
+    for (int s0 = wave * 64; s0 < Qpad * 2 * NB; s0 += 256) {        // dY: 2 * NB 16-B slots per position
+      const int s = s0 + lane;
+      const int q = s / (2 * NB), g = s - q * (2 * NB);
+      const int r = fast_div(q, Wp, inv_wp);
+      const int xx = q - r * Wp - (KS == 3 ? 1 : 0), y = y0 + r;
+      const void* src = zero;
+      if (q < Q && (unsigned)xx < (unsigned)W && y < H && g * 8 < p.Cout)
+        src = dy + ((ibase + (size_t)y * W + xx) * (size_t)p.Cout + (size_t)(g * 8));
+      glds16(src, b + s0 * 16);
+    }
+    char* pb = b + Qpad * DYB;
+    for (int s0 = wave * 64; s0 < prow * CG; s0 += 256) {            // X: CG slots per patch position
+      const int s = s0 + lane;
+      const int pr = s / CG, g = s - pr * CG;
+      const int pi = pr - (KS == 3 ? 1 : 0);                         // patch row 0 is a spare zero row (tap -W-3)
+      const int rr = pi >= 0 ? fast_div(pi, Wp, inv_wp) : 0;
+      const int xx = pi - rr * Wp - (KS == 3 ? 1 : 0);
+      const int y = y0 + rr - (KS == 3 ? 1 : 0);
+      const void* src = zero;
+      if (pi >= 0 && rr < R + (KS == 3 ? 2 : 0) && (unsigned)xx < (unsigned)W && (unsigned)y < (unsigned)H)
+        src = x + ((ibase + (size_t)y * W + xx) * (size_t)C + (size_t)(g * 8));
+      glds16(src, pb + s0 * 16);
+    }
+  };
+
+  // ---- this wave's accumulator blocks: block b = nb * JB + jb for b = wave, wave + 4, ... ----
+  const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+  int a_col[MAXB], b_col[MAXB], b_off[MAXB];      // byte columns of the lane's 8-B piece; X row offset (or the zero rows)
+  bool b_zero[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int blk = wave + 4 * i;
+    const int nb = blk / JB, jb = blk - nb * JB;
+    a_col[i] = nb * 32 + tp * 8;
+    const int j0 = jb * 16 + tp * 4;                // this lane's 4 columns j0..j0+3 share a tap (C >= 8)
+    const int tap = j0 / C, c = j0 - tap * C;
+    b_col[i] = c * 2;
+    b_zero[i] = j0 >= J;
+    const int ky = tap / KS, kx = tap - ky * KS;
+    b_off[i] = KS == 3 ? ky * Wp + kx : 0;          // LDS row of position q under tap (ky,kx): (q + ky*Wp + kx - 1) + 1
+  }
+  f32x4_t acc[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue(tile, smem);
+  int cur = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, smem + (cur ^ 1) * buf_bytes);
+    const char* dyp = smem + cur * buf_bytes;
+    const char* pat = dyp + Qpad * DYB;
+    for (int qc = 0; qc < Qpad; qc += 32) {
+      const int row = qc + 8 * fq + tq;
+#pragma unroll
+      for (int i = 0; i < MAXB; ++i) {
+        if (wave + 4 * i < NBLK) {
+          const bf16x8_t fa = tr_read8(dyp, row, DYB, a_col[i]);
+          const bf16x8_t fb = tr_read8(pat, b_zero[i] ? prow - 8 + tq : row + b_off[i], PXB, b_zero[i] ? 0 : b_col[i]);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    cur ^= 1;
+  }
+  // ---- one flush per workgroup ----
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int blk = wave + 4 * i;
+    if (blk >= NBLK) continue;
+    const int nb = blk / JB, jb = blk - nb * JB;
+    const int j = jb * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb * 16 + fq * 4 + r;
+      if (n < p.Cout && j < J) atomicAdd(p.dw + (size_t)n * J + j, acc[i][r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // dgrad weight packing: wt[ci][ky][kx][co] <- w[co][ky][kx][ci], all layers at once.
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -1977,6 +2104,72 @@ void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, st, q);
 }
 
+template <int CG, int NB, int KS>
+void launch_wgrad_small(const WgradParams& p, int R, hipStream_t st) {
+  const int W = p.seg[0].dst_w, H = p.seg[0].dst_h;
+  const int Wp = KS == 3 ? W + 2 : W;
+  const int Qpad = (R * Wp + 31) & ~31;
+  int prow = Qpad + (KS == 3 ? 2 * Wp + 3 : 0) + 8;            // furthest tap of the last position + 8 zero rows
+  const int unit = 64 / CG;                                    // whole 1-KB LDS-DMA bursts
+  prow = (prow + unit - 1) / unit * unit;
+  const int buf_bytes = Qpad * 32 * NB + prow * 16 * CG;
+  const int tiles_per_img = (H + R - 1) / R;
+  const int ntiles = p.batch * tiles_per_img;
+  int grid = 2 * p.cu_budget;                                  // persistent: one flush per workgroup
+  if (grid > ntiles) grid = ntiles;
+  const size_t lds = (size_t)2 * buf_bytes;
+  auto kern = conv_wgrad_small_kernel<CG, NB, KS>;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, R, tiles_per_img, ntiles, buf_bytes, prow);
+}
+
+// wide, shallow layers: Cin in {8,16,32}, Cout <= 64, 3x3/s1/p1 or 1x1/s1, one level, >= 2^15 pixels, no bias gradient
+bool dispatch_wgrad_small(const WgradParams& p, const kd6d_conv_geom* g, hipStream_t st) {
+  const char* env = getenv("KD6D_WGRAD_SMALL");                // tuning / test aid, read per call: 0 = off, 1 = any size
+  const int force = env ? atoi(env) : -1;
+  if (force == 0 || p.dbias != nullptr || g->nseg != 1 || p.stride != 1) return false;
+  if (!((p.ks == 3 && p.pad == 1) || (p.ks == 1 && p.pad == 0))) return false;
+  if ((p.Cin != 8 && p.Cin != 16 && p.Cin != 32) || p.Cout > 64 || (p.Cout & 7)) return false;
+  const kd6d_seg& q = g->seg[0];
+  if (q.in_row0 != 0 || q.out_row0 != 0 || q.in_w > 256) return false;
+  // measured (tools/bench_conv.py, B = 16): the 1x1 layers gain (64x64 map, 16 -> 8 channels: 16.2 -> 7.5 us); the
+  // 3x3 layers do NOT -- a tile is one DMA round trip of ~3 us for ~0.3 us of MFMA work and the persistent grid
+  // that keeps the atomic flush small also keeps too few round trips in flight (256x256x8->8: 46 -> 45 us,
+  // 128x128x8->16: 26 -> 31, 64x64x8->64: 21 -> 20; more workgroups: slower, the flush serialises).  They stay
+  // on the general kernel unless forced; a deeper DMA ring per workgroup is the open improvement.
+  if (force < 0 && (p.M < (1 << 15) || p.ks != 1)) return false;
+  const int W = q.in_w, H = q.in_h;
+  int R = 512 / W;                     // ~512 positions per tile (256: 9.5 us on the 16 -> 8 layer, 512: 7.5)
+  if (R < 1) R = 1;
+  if (R > H) R = H;
+  const int nb = (p.Cout + 15) / 16;
+  const int cg = p.Cin / 8;
+  auto lds_bytes = [&](int r) {        // as launch_wgrad_small sizes the two buffers
+    const int wp = p.ks == 3 ? W + 2 : W;
+    const int qpad = (r * wp + 31) & ~31;
+    int prow = qpad + (p.ks == 3 ? 2 * wp + 3 : 0) + 8;
+    const int unit = 64 / cg;
+    prow = (prow + unit - 1) / unit * unit;
+    return (size_t)2 * ((size_t)qpad * 32 * nb + (size_t)prow * 16 * cg);
+  };
+  while (R > 1 && lds_bytes(R) > 72 * 1024) R >>= 1;           // two workgroups per CU
+  if (lds_bytes(R) > 144 * 1024) return false;
+#define KD6D_WS_CASE(CG_, NB_, KS_) \
+  if (cg == CG_ && nb == NB_ && p.ks == KS_) { launch_wgrad_small<CG_, NB_, KS_>(p, R, st); return true; }
+  KD6D_WS_CASE(1, 1, 3) KD6D_WS_CASE(1, 2, 3) KD6D_WS_CASE(1, 4, 3)
+  KD6D_WS_CASE(2, 1, 3) KD6D_WS_CASE(2, 2, 3) KD6D_WS_CASE(2, 4, 3)
+  KD6D_WS_CASE(4, 1, 3) KD6D_WS_CASE(4, 2, 3) KD6D_WS_CASE(4, 4, 3)
+  KD6D_WS_CASE(1, 1, 1) KD6D_WS_CASE(2, 1, 1) KD6D_WS_CASE(4, 1, 1)
+  KD6D_WS_CASE(1, 2, 1) KD6D_WS_CASE(2, 2, 1) KD6D_WS_CASE(4, 2, 1)
+  KD6D_WS_CASE(1, 4, 1) KD6D_WS_CASE(2, 4, 1) KD6D_WS_CASE(4, 4, 1)
+#undef KD6D_WS_CASE
+  return false;
+}
+
 void dispatch_wgrad_tr(const WgradParams& p, hipStream_t st) {
   if (p.Cout <= 16) launch_wgrad_tr<16, 1, 4>(p, st);
   else if (p.Cout <= 32) launch_wgrad_tr<32, 1, 4>(p, st);
@@ -2085,7 +2278,7 @@ extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void*
   p.cu_budget = (cu_budget == 0 || cu_budget > ncu) ? ncu : cu_budget;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    dispatch_wgrad_tr(p, st);
+    if (!dispatch_wgrad_small(p, g, st)) dispatch_wgrad_tr(p, st);
   } else {
     dispatch_wgrad<float>(p, st);
     if (dbias) {           // exact-fp32 parity path: separate column-sum pass

@@ -207,6 +207,39 @@ def test_conv_wgrad(gpu_device, dtype, case):
     torch.testing.assert_close(db.cpu().double(), ref_b, rtol=2e-4, atol=2e-4 * max(float(ref_b.abs().max()), 1.0))
 
 
+@pytest.mark.parametrize("case", [
+    # (B, Cin, Cout, k, levels): the persistent padded-patch kernel for small dW (Cin in {8,16,32}, Cout <= 64, no bias)
+    (2, 8, 8, 3, [(256, 256)]),
+    (2, 8, 16, 3, [(128, 128)]),
+    (4, 16, 8, 1, [(64, 64)]),
+    (4, 8, 64, 3, [(64, 64)]),
+    (2, 32, 64, 3, [(64, 64)]),
+    (2, 32, 40, 1, [(64, 64)]),
+    (3, 16, 24, 3, [(9, 7)]),          # ragged: tiles shorter than the image, odd width
+    (2, 8, 8, 3, [(3, 300)]),          # wider than 256: stays on the general kernel
+])
+def test_conv_wgrad_small_layers(gpu_device, case, monkeypatch):
+    ops = _ops()
+    monkeypatch.setenv("KD6D_WGRAD_SMALL", "1")
+    dtype = torch.bfloat16
+    B, Cin, Cout, k, levels = case
+    g = torch.Generator().manual_seed(3 + Cout)
+    pad = k // 2
+    geom = ops.Geom(B, Cin, Cout, k, 1, pad, levels)
+    xs = [round_to(torch.randn(B, Cin, h, w_, generator=g), dtype) for (h, w_) in levels]
+    dys = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
+    dev = gpu_device
+    dw = torch.full((Cout, k, k, Cin), 0.25, dtype=torch.float32, device=dev)        # the call accumulates
+    for budget in (0, 16):
+        ops.conv2d_wgrad(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), dw, cu_budget=budget)
+    torch.cuda.synchronize()
+    ref = torch.zeros(Cout, Cin, k, k)
+    for x, dy in zip(xs, dys):
+        ref += torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=1, padding=pad)
+    got = (dw.cpu().permute(0, 3, 1, 2) - 0.25) / 2
+    torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4 * max(float(ref.abs().max()), 1.0))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [
     # (B, Cin, Cout, k, stride, levels, groups)   groups 0 = per-channel (BatchNorm) statistics
