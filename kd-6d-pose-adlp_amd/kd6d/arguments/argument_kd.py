@@ -61,6 +61,7 @@ def get_argparser():
                         "the next batch with the student step of the current one; eager: launch kernel by kernel")
     p.add_argument("--batch_size", type=int, default=0, help="global batch; 0 = SOLVER.IMS_PER_BATCH")
     p.add_argument("--image_size", type=int, default=256, help="synthetic crop size")
+    p.add_argument("--val_freq", type=int, default=0, help="validate every N steps; 0 = the backbone's default")
     return p
 
 
@@ -86,6 +87,8 @@ def build_cfgs(args):
     cfg["SOLVER"]["BASE_LR"] = args.base_lr
     if args.batch_size > 0:
         cfg["SOLVER"]["IMS_PER_BATCH"] = args.batch_size
+    if args.val_freq > 0:
+        cfg["SOLVER"]["VAL_FREQ"] = args.val_freq
     cfg.setdefault("KD", {})
     cfg["KD"]["LOSS_WEIGHT_KD"] = args.kd_weight
     cfg["KD"]["LEVEL"] = args.kd_level

@@ -6,8 +6,10 @@ train_kd.py:34-171, on the MI355X-native kd6d step.
         --kd_weight 5. --max_iters 10000 --working_dir outputs/ape/kd/ --synthetic
 
 Multi-GPU: python -m torch.distributed.run --nproc-per-node N train_kd.py ...  (one process per
-GPU, backend nccl = RCCL).  The BOP/LINEMOD reader and the evaluation path of the reference are
-outside the hot path; without --synthetic this script stops with a clear message.
+GPU, backend nccl = RCCL).  The BOP/LINEMOD reader of the reference is outside the hot path (SURVEY.md
+8(f)-4); without --synthetic this script stops with a clear message.  Every VAL_FREQ steps rank 0 runs the
+evaluation path (kd6d/libs/eval_libs.valid: eval forward -> pose candidates -> PnP-RANSAC -> ADI / REP) on
+held-out synthetic batches, the 3D-box corners standing in for the meshes.
 """
 import json
 import os
@@ -24,6 +26,7 @@ import torch  # noqa: E402
 from kd6d.arguments.argument_kd import get_args  # noqa: E402
 from kd6d.kd_losses import PackedTargets  # noqa: E402
 from kd6d.libs.distributed import get_rank, shard_batch, synchronize  # noqa: E402
+from kd6d.libs.eval_libs import valid  # noqa: E402
 from kd6d.libs.poses import ImageList  # noqa: E402
 from kd6d.libs.train_libs import build_model, build_model_teacher  # noqa: E402
 from kd6d.models.model_kd import PoseModuleKD as PoseModule  # noqa: E402
@@ -40,6 +43,21 @@ def synthetic_loader(cfg, device, n_batches=8):
     while True:
         for b in batches:
             yield b
+
+
+def synthetic_valid_loader(cfg, device, n_batches=2):
+    """(images, PackedTargets, meta_infos) of held-out seeded batches + surrogate meshes (the 8 box corners)."""
+    per_gpu = shard_batch(cfg["SOLVER"]["IMS_PER_BATCH"])
+    size = cfg["RUNTIME"].get("IMAGE_SIZE", 256)
+    loader, meshes = [], None
+    for i in range(n_batches):
+        images, targets = make_batch(per_gpu, 900000 + i, crop=size)
+        metas = [{"path": "val%d_%d" % (i, j), "K": t.K.numpy(), "class_ids": [int(c) for c in t.class_ids],
+                  "rotations": [r.numpy() for r in t.rotations],
+                  "translations": [x.numpy().reshape(3, 1) for x in t.translations]} for j, t in enumerate(targets)]
+        meshes = [targets[0].keypoints_3d[c].numpy() for c in range(cfg["DATASETS"]["N_CLASS"] - 1)]
+        loader.append((images.to(device), PackedTargets(targets, device), metas))
+    return loader, meshes
 
 
 if __name__ == "__main__":
@@ -66,6 +84,7 @@ if __name__ == "__main__":
         raise SystemExit("the BOP/LINEMOD reader is outside the KD-step hot path (SURVEY.md 8(f)-4); "
                          "run with --synthetic")
     train_loader = synthetic_loader(cfg, device)
+    valid_loader, valid_meshes = synthetic_valid_loader(cfg, device)
     cfg["KD"]["vis_dir"] = cfg["RUNTIME"]["WORKING_DIR"]
 
     print("Building teacher ......")
@@ -130,6 +149,11 @@ if __name__ == "__main__":
                 total_steps, cfg["SOLVER"]["MAX_ITER"], optimizer.param_groups[0]["lr"], float(loss_cls),
                 float(loss_reg), float(loss_kd), idx * cfg["SOLVER"]["IMS_PER_BATCH"] / max(dt, 1e-9)))
         if get_rank() == 0 and total_steps % VAL_FREQ == 0:
+            acc = valid(cfg, total_steps, valid_loader, model, device, valid_meshes)     # train_kd.py:148-150
+            model.train()
+            seen = [a for a in acc[0] if a]
+            print("valid @ %d: %s" % (total_steps, {k: round(float(sum(a[k] for a in seen)) / len(seen), 2) for k in seen[0]}
+                                      if seen else "no objects"))
             torch.save({"steps": total_steps, "model": model.state_dict(), "optim": optimizer.state_dict(),
                         "sched": scheduler.state_dict()}, os.path.join(wd, "latest.pth"))
     if get_rank() == 0:
