@@ -322,6 +322,8 @@ class PoseNet:
         self._bufs, self._scratch_off, self._scratch_size, self.scratch_buf = {}, {}, 0, None
         self.wt = None
         self.training = True
+        self.in_hw = None
+        self.levels, self.batch = None, None
         self.side_stream = None        # set (e.g. by GraphedKDStep) to run weight gradients concurrently
         self.side_streams = None       # optional list: consecutive weight gradients rotate over these streams
         self.wgrad_cu_budget = 0       # CUs each forked weight gradient aims to fill (0 = the device)
@@ -565,6 +567,7 @@ class PoseNet:
             r += B * h * w
         head_in = self.buf("head_in", (r, oc))
         self.levels, self.rows, self.level_row0, self.batch = levels_all, r, row0, B
+        self.in_hw = (H, W)
 
         def slot(li):
             h, w = levels_all[li]

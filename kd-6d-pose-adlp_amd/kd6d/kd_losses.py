@@ -234,13 +234,13 @@ class KDLoss:
         self.cap = cap
         self.ctx = None
 
-    def forward(self, cls_s, reg_s, levels, batch, tgt, teacher, keys=None, seg_scale=None):
-        dev = cls_s.device
-        rows = cls_s.shape[0]
+    def assign(self, levels, batch, tgt, keys=None):
+        """SSC target assignment + the zeroed per-step workspaces.  Depends on the targets only, not on the student's
+        output: the graphed step runs it on a side stream beside the student's forward."""
+        dev = tgt.mask.device
+        rows = batch * sum(h * w for h, w in levels)
         cap = self.cap
         lv = make_levels(batch, levels)
-        if self.diameters is None or self.diameters.device != dev:
-            self.diameters = torch.tensor(self.diameters_host, dtype=torch.float32, device=dev)
         if keys is None:
             keys = torch.rand(rows, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -251,15 +251,32 @@ class KDLoss:
         # one zero fill per dtype for every per-step accumulator / slot array of the loss side
         wf = torch.zeros(8 + bp + n * 64, **f32)
         wi = torch.zeros(3 * bp + 4 + 2 * n, **i32)
+        pos_cnt = wi[0:batch]
+        pos_row, pos_gt = wi[3 * bp + 4:3 * bp + 4 + n], wi[3 * bp + 4 + n:3 * bp + 4 + 2 * n]
+        P = ops._ptr
+        check(lib.kd6d_ssc_assign(ctypes.byref(lv), P(tgt.mask), tgt.mask_h, tgt.mask_w, P(tgt.kp3d), P(tgt.K),
+                                  P(tgt.class_ids), P(tgt.n_gt), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
+                                  P(keys), self.positive_num, self.positive_lambda, cap, P(labels), P(pos_cnt),
+                                  P(pos_row), P(pos_gt), ops._stream()), "kd6d_ssc_assign")
+        return dict(rows=rows, levels=tuple(levels), batch=batch, labels=labels, wf=wf, wi=wi, keys=keys)
+
+    def forward(self, cls_s, reg_s, levels, batch, tgt, teacher, keys=None, seg_scale=None, pre=None):
+        dev = cls_s.device
+        rows = cls_s.shape[0]
+        cap = self.cap
+        lv = make_levels(batch, levels)
+        if self.diameters is None or self.diameters.device != dev:
+            self.diameters = torch.tensor(self.diameters_host, dtype=torch.float32, device=dev)
+        if pre is None or pre["rows"] != rows or pre["levels"] != tuple(levels) or pre["batch"] != batch:
+            pre = self.assign(levels, batch, tgt, keys)
+        labels, wf, wi = pre["labels"], pre["wf"], pre["wi"]
+        n = batch * cap
+        bp = (batch + 3) // 4 * 4
         pos_cnt, valid, s_start = wi[0:batch], wi[bp:bp + batch], wi[2 * bp:2 * bp + batch]
         n_valid = wi[3 * bp:3 * bp + 1]
         pos_row, pos_gt = wi[3 * bp + 4:3 * bp + 4 + n], wi[3 * bp + 4 + n:3 * bp + 4 + 2 * n]
         st = ops._stream()
         P = ops._ptr
-        check(lib.kd6d_ssc_assign(ctypes.byref(lv), P(tgt.mask), tgt.mask_h, tgt.mask_w, P(tgt.kp3d), P(tgt.K),
-                                  P(tgt.class_ids), P(tgt.n_gt), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
-                                  P(keys), self.positive_num, self.positive_lambda, cap, P(labels), P(pos_cnt),
-                                  P(pos_row), P(pos_gt), st), "kd6d_ssc_assign")
         losses = wf[0:4]                       # cls, reg, kd, (pad)
         loss_img = wf[8:8 + batch]
         o = 8 + bp

@@ -193,17 +193,27 @@ class PoseModuleKD(nn.Module):
         st = net.store
         st.ensure_grads()
         ops.mark("student.fwd.start")
-        cls, reg = net.forward(x)
-        ops.mark("student.fwd.end")
         tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
+        # the SSC assignment reads the targets only: fork it beside the forward when a side stream exists and the
+        # shapes are those of the previous step (the level grid is known only after a first forward)
+        pre, side = None, net.side_stream
+        keys = getattr(self, "_debug_keys", None)
+        if side is not None and net.levels is not None and net.batch == B and net.in_hw == tuple(x.shape[-2:]):
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pre = self.loss_evaluator.assign(net.levels, B, tgt, keys)
+        cls, reg = net.forward(x)
+        if pre is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        ops.mark("student.fwd.end")
         if isinstance(pred_t, kd_losses.DeferredTeacher):      # teacher ran concurrently on another stream
             pred_t = pred_t.join()
         teacher = pred_t if isinstance(pred_t, TeacherKnowledge) else None
         if pred_t is not None and teacher is None:
             raise TypeError("pred_t must come from a kd6d teacher forward (TeacherKnowledge)")
-        losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher,
-                                             keys=getattr(self, "_debug_keys", None),
-                                             seg_scale=st.storage(net.scales))
+        losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher, keys=keys,
+                                             seg_scale=st.storage(net.scales), pre=pre)
         ops.mark("student.loss.end")
         self._nbt += 1
         return losses
