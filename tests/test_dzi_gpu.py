@@ -45,3 +45,28 @@ def test_dzi_crop_feeds_the_step_inputs(gpu_device):
     assert img.shape == (B, 3, 256, 256) and img.dtype == torch.float32 and msk.shape == (B, 256, 256)
     assert tr.shape == (B, 2, 3) and float(tr[0, 0, 0]) == pytest.approx(256 / s)
     assert bool(torch.isfinite(img).all())
+
+
+def test_bop_reader_feeds_the_gpu_front_end(gpu_device, tmp_path):
+    """BOP tree -> BOP_Dataset -> collate_frames -> DZI boxes from the projected 3D boxes -> kd6d_dzi_crop ->
+    PackedTargets: the reader's output is what the GPU front-end and the step take."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from bop_fixture import write_tree
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs import dataset as D
+    from kd6d.libs import dzi_libs as Dz
+    from kd6d.libs.poses import PoseAnnot
+    t = write_tree(str(tmp_path))
+    ds = D.BOP_Dataset(t["list_file"], t["models"], t["bbox"], training=False)
+    frames, masks, targets, metas = D.collate_frames([ds[0], ds[1]])
+    H, W = frames.shape[1:3]
+    cs = [Dz.test_bbox_DZI(D.projected_box(tg, 0), H, W) for tg in targets]
+    img, msk, tr, sc = Dz.dzi_batch(frames.to(gpu_device), masks.to(gpu_device), [c for c, _ in cs], [s for _, s in cs],
+                                    Dz.normalize_lut(MEAN, STD, gpu_device), input_res=64)
+    assert img.shape == (2, 3, 64, 64) and bool(torch.isfinite(img).all()) and msk.shape == (2, 64, 64)
+    crops = [PoseAnnot(tg.keypoints_3d, tg.K, msk[i].cpu(), tg.class_ids, tg.rotations, tg.translations, 64, 64,
+                       sc[i].cpu(), tr[i].cpu()) for i, tg in enumerate(targets)]
+    packed = PackedTargets(crops, gpu_device)
+    assert packed.mask.shape == (2, 64, 64) and packed.bbox_trans.shape == (2, 2, 3) and int(packed.n_gt[0]) == 2
