@@ -299,6 +299,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
   const int fr = lane & 15;
   const int fq = lane >> 4;
   const bool vec_ok = (p.N & 3) == 0;
+  // per-channel epilogue parameters of this lane's channels, loaded ONCE (they do not depend on the pixel):
+  // identity where absent, so the pixel loop below is branch-free in them
+  constexpr bool HOIST = CI <= 4;
+  f32x4_t hsc[HOIST ? CI : 1], hsh[HOIST ? CI : 1];
+  if (HOIST && vec_ok) {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
+      hsc[c] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+      hsh[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) {
+        if (p.ch_scale) hsc[c] = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+        if (p.ch_shift) hsh[c] = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+      }
+    }
+  }
 #pragma unroll
   for (int q = 0; q < PI; ++q) {
     const int m = m0 + wp * (BP / WP) + q * 16 + fr;
@@ -320,15 +336,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
       float v[4] = {acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]};
       const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
       if (vec_ok) {
-        if (p.ch_scale) {
-          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+        if (HOIST) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= s4[r];
-        }
-        if (p.ch_shift) {
-          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * hsc[c][r] + hsh[c][r];
+        } else {
+          if (p.ch_scale) {
+            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += s4[r];
+            for (int r = 0; r < 4; ++r) v[r] *= s4[r];
+          }
+          if (p.ch_shift) {
+            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += s4[r];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
