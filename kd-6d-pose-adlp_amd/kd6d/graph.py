@@ -55,6 +55,7 @@ class GraphedKDStep:
         self.images = self.tgt = self.losses = None        # the batch the student trains on
         self.images_nxt = self.tgt_nxt = None              # pipeline: the batch the teacher looks at
         self.t_cur = None                                  # pipeline: teacher cells of `images`
+        self._blocks = None                                # pipeline: [current, next] hand-over blocks
         self.pending = False
 
     # ---- the body the reference's loop runs per iteration (train_kd.py:104-137) ----------
@@ -92,9 +93,39 @@ class GraphedKDStep:
 
     def _advance(self, pred_nxt):
         """k -> k+1: what the teacher just saw becomes the student's next batch."""
+        if self._blocks is not None:         # everything handed over lives in one block per side: ONE copy
+            self._blocks[0].copy_(self._blocks[1], non_blocking=True)
+            for key in ("post_kp_2d", "post_kp_cls", "post_pos_per_img"):
+                self.t_cur.pop(key, None)
+            return
         self.t_cur.copy_from(pred_nxt)
         self.images.tensors.copy_(self.images_nxt.tensors, non_blocking=True)
         self.tgt.copy_from(self.tgt_nxt)
+
+    def _make_blocks(self):
+        """Re-home images, targets and teacher cells of the current / next batch in two byte blocks of identical
+        layout, so that the hand-over at the end of a step is one device copy instead of six."""
+        from .kd_losses import TeacherKnowledge
+        dev = self.images.tensors.device
+        parts = [self.images.tensors, self.tgt.mask, self.tgt.flat_f, self.tgt.flat_i, self.t_cur.flats[0], self.t_cur.flats[1]]
+        offs, total = [], 0
+        for t in parts:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        blocks = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+        def views(block):
+            return [block[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(offs, parts)]
+
+        cur, nxt = views(blocks[0]), views(blocks[1])
+        for side, images, tgt in ((cur, self.images, self.tgt), (nxt, self.images_nxt, self.tgt_nxt)):
+            side[0].copy_(images.tensors)
+            images.tensors = side[0]
+            tgt.rebind_storage(side[1], side[2], side[3])
+        cur[4].copy_(self.t_cur.flats[0]); cur[5].copy_(self.t_cur.flats[1])
+        self.t_cur = TeacherKnowledge.from_flats(cur[4], cur[5], self.t_cur.batch, self.t_cur.cap)
+        self.teacher._teacher_flats = (nxt[4], nxt[5])     # the teacher's selection writes straight into the next block
+        self._blocks = blocks
 
     # ---- static inputs ------------------------------------------------------------------------
     def _load(self, images, tgt):
@@ -138,6 +169,8 @@ class GraphedKDStep:
 
     def _capture(self):
         self.student._defer_allreduce = True
+        if self.pipeline and type(self) is GraphedKDStep and self._blocks is None:
+            self._make_blocks()
         snap = self._snapshot()                              # the warm-up steps below must not train
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

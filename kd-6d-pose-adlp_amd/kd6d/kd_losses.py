@@ -105,6 +105,14 @@ class PackedTargets:
         self.flat_f.copy_(other.flat_f, non_blocking=True)
         self.flat_i.copy_(other.flat_i, non_blocking=True)
 
+    def rebind_storage(self, mask, flat_f, flat_i):
+        """Move the three device buffers into caller-owned storage of the same shapes (contents are copied)."""
+        for new, old in ((mask, self.mask), (flat_f, self.flat_f), (flat_i, self.flat_i)):
+            assert new.shape == old.shape and new.dtype == old.dtype
+            new.copy_(old)
+        self.mask, self.flat_f, self.flat_i = mask, flat_f, flat_i
+        self._rebind()
+
     @staticmethod
     def teacher_view(tgt, groups):
         """What the teacher's forward reads of the targets (the crop affines, postprocess_kd.py:171-179) for
@@ -129,12 +137,17 @@ class TeacherKnowledge(dict):
         self.t_start = torch.arange(batch, dtype=torch.int32, device=t_cnt.device) * cap
         self.flats = flats            # (fp32, int32) buffers all the slot arrays are views of
 
+    @staticmethod
+    def from_flats(wf, wi, batch, cap):
+        """Slot arrays as views of one fp32 (n*48) and one int32 (n + batch rounded up to 4) buffer."""
+        n, b = batch * cap, batch
+        return TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
+                                wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), cap, b, (wf, wi))
+
     def clone_static(self):
         """Persistent copy (own storage) that `copy_from` refreshes: the double buffer of the step pipeline."""
         wf, wi = (t.clone() for t in self.flats)
-        n, b = self.batch * self.cap, self.batch
-        return TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
-                                wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), self.cap, b, (wf, wi))
+        return TeacherKnowledge.from_flats(wf, wi, self.batch, self.cap)
 
     def slice_static(self, j, groups):
         """Persistent TeacherKnowledge for ONE batch out of a result computed on `groups` batches at once."""
@@ -189,12 +202,19 @@ class DeferredTeacher:
 
 
 def teacher_select(cls_t, reg_t, levels, batch, bbox_trans, th=0.1, positive_num=10, positive_lambda=1.0, cap=CAP,
-                   frame_wh=(640.0, 480.0)):
+                   frame_wh=(640.0, 480.0), flats=None):
+    """flats: optional caller-owned (fp32 n*48, int32 n + batch rounded up to 4) output buffers (the step pipeline
+    keeps them inside its hand-over block); zeroed here."""
     dev = cls_t.device
     lv = make_levels(batch, levels)
     n = batch * cap
-    wf = torch.zeros(n * 48, dtype=torch.float32, device=dev)        # one fill for all fp32 outputs
-    wi = torch.zeros(n + (batch + 3) // 4 * 4, dtype=torch.int32, device=dev)
+    if flats is None:
+        wf = torch.zeros(n * 48, dtype=torch.float32, device=dev)        # one fill for all fp32 outputs
+        wi = torch.zeros(n + (batch + 3) // 4 * 4, dtype=torch.int32, device=dev)
+    else:
+        wf, wi = flats
+        assert wf.numel() == n * 48 and wi.numel() == n + (batch + 3) // 4 * 4
+        wf.zero_(); wi.zero_()
     t_kp, t_kp_n = wf[0:n * 16].view(n, 8, 2), wf[n * 16:n * 32].view(n, 8, 2)
     t_score, t_beta = wf[n * 32:n * 40].view(n, 8), wf[n * 40:n * 48].view(n, 8)
     t_row, t_cnt = wi[0:n], wi[n:n + batch]

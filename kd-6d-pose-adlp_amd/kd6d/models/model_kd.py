@@ -180,7 +180,8 @@ class PoseModuleKD(nn.Module):
             cls, reg = net.forward(x)
             tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
             return kd_losses.teacher_select(cls, reg, net.levels, B, tgt.bbox_trans, self.inference_th,
-                                            self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh)
+                                            self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh,
+                                            flats=getattr(self, "_teacher_flats", None))
         # evaluation: candidate cells per ground-truth class on the GPU, PnP-RANSAC on the host (models/model_kd.py:94-95)
         cls, reg = net.forward(x)
         tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
