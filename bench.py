@@ -92,7 +92,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # KD6D_EXCHANGE_SINGLE_RANK=1 under `torch.distributed.run --nproc-per-node 1`: rehearse the N > 1 code path
+    # (RCCL communicator, the all-reduce between the two graphs, barriers) on one GPU
+    use_pg = world > 1 or (os.environ.get("KD6D_EXCHANGE_SINGLE_RANK") == "1" and "MASTER_ADDR" in os.environ)
+    if use_pg:
         dist.init_process_group(backend="nccl", init_method="env://")
 
     from kd6d import backbone as BB, ops
@@ -113,8 +116,8 @@ def main():
     student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
     student.net.reset_parameters(seed=1)
     student = student.to(dev).train()
-    if world > 1:
-        D.broadcast_(student.net.store.params, 0)
+    if use_pg:
+        dist.broadcast(student.net.store.params, 0)
         student.net.invalidate()
     base_lr = 1e-3 / world                      # libs/train_libs.py:117
     opt = FusedClipAdamW(student, lr=base_lr, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
@@ -167,7 +170,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -175,10 +178,10 @@ def main():
         ld = step(args.warmup + i)
     t_enqueued = time.perf_counter() - t0          # host-side launch time (the GPU runs behind)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -264,7 +267,7 @@ def main():
         # ---- CPU baseline leg (oracle = port of the reference step), rank 0, N=1 only ----
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, B, full)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

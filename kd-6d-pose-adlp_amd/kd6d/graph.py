@@ -193,7 +193,7 @@ class GraphedKDStep:
         self._restore(snap)
 
     def _exchange(self):
-        if D.get_world_size() > 1:
+        if D.exchange_active():
             st = self.student.net.store
             D.allreduce_mean_(st.grads[:st.n_train])
 

@@ -6,6 +6,7 @@ collective per step: a mean all-reduce of the single flat fp32 gradient bucket (
 elements) -- latency-bound at these sizes, so one bucket, no overlap machinery.
 """
 import math
+import os
 
 import torch
 from torch import distributed as dist
@@ -29,10 +30,19 @@ def synchronize():
         dist.barrier()
 
 
+def exchange_active():
+    """True when the per-step gradient exchange has to run: more than one rank, or a one-rank process group with
+    KD6D_EXCHANGE_SINGLE_RANK=1 (a rehearsal of the RCCL path -- communicator set-up, the collective between the
+    two replayed graphs, the barriers -- on a box with one GPU)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("KD6D_EXCHANGE_SINGLE_RANK") == "1"
+
+
 def allreduce_mean_(flat):
     """In-place mean over ranks of one flat bucket."""
     n = get_world_size()
-    if n == 1:
+    if not exchange_active():
         return flat
     if dist.get_backend() == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
