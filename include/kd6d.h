@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 4
+#define KD6D_ABI_VERSION 5
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -146,6 +146,21 @@ int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz,
                             const float* mean, const float* invstd, const float* gamma, const float* beta,
                             int act, const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
                             float* dbeta, int replicas, void* stream);
+
+/* BN(train) + activation + MaxPool2d(2,2) in one pass: the last ConvBlock of a darknet-tiny stage and the pool
+ * behind it (backbone/darknet.py:94-97).  x: (B,H,W,C) conv output; y / dy: the POOLED tensors (B,H/2,W/2,C);
+ * dx: gradient of x.  The un-pooled activation and its gradient are never stored: the backward re-derives each
+ * 2x2 window from x with the forward's arithmetic and rounding and sends dy to the first maximum in row-major
+ * window order (MaxPool2d's rule).  Statistics, saved mean / invstd, replicas and workspaces as in the unpooled
+ * entry points above; kd6d_bn_pool_train_bwd runs the reduction and the apply pass. */
+int kd6d_bn_pool_train_fwd(int dtype, int x_f32, const void* x, void* y, int B, int H, int W, int C,
+                           const float* sum, const float* sumsq, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* save_mean,
+                           float* save_invstd, int act, void* stream);
+int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, void* dx, int B, int H, int W,
+                           int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           int act, float* sum_dy, float* sum_dy_xhat, float* dgamma, float* dbeta, int replicas,
+                           void* stream);
 
 /* GroupNorm(groups)+ReLU of the PoseHead towers (models/model.py:395-417) over a multi-level
  * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 floats per

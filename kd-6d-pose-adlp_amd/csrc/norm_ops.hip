@@ -109,6 +109,19 @@ __device__ __forceinline__ void load_x<float, 8>(const float* __restrict__ base,
   granule_to_f32<float>(reinterpret_cast<const u32x4_t*>(base)[2 * g + 1], v + 4);
 }
 
+// act(v * sc + sh) with an explicit fma: the pooled kernels below recompute it in the backward pass and have to
+// reproduce the forward value bit for bit (the argmax of a 2x2 window must not depend on a contraction choice)
+__device__ __forceinline__ float bn_act(float v, float sc, float sh, int act) {
+  float t = __builtin_fmaf(v, sc, sh);
+  if (act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+  else if (act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+  return t;
+}
+__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
+  sc = gamma * invstd;
+  sh = __builtin_fmaf(-mean, sc, beta);
+}
+
 // y = act(gamma * (x - mean) * invstd + beta), mean/var from the batch sums.
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
@@ -127,8 +140,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     float var = sumsq[c] * inv_rows - m * m;
     var = fmaxf(var, 0.f);
     const float is = rsqrtf(var + eps);
-    sc[e] = gamma[c] * is;
-    sh[e] = beta[c] - m * sc[e];
+    bn_scale_shift(m, is, gamma[c], beta[c], sc[e], sh[e]);
   }
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += kThreads) {
@@ -147,12 +159,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     float v[EG];
     load_x<TX, EG>(x, g, v);
 #pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      float t = v[e] * sc[e] + sh[e];
-      if (act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
-      else if (act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
-      v[e] = t;
-    }
+    for (int e = 0; e < EG; ++e) v[e] = bn_act(v[e], sc[e], sh[e], act);
     yg[g] = f32_to_granule<T>(v);
   }
 }
@@ -267,6 +274,215 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
       dv[e] = ga[e] * is[e] * (d - k1[e] - xh * k2[e]);
     }
     og[g] = f32_to_granule<T>(dv);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// BN (train) + activation + MaxPool2d(2,2) in one pass -- the last block of a darknet-tiny stage followed by
+// the pool (backbone/darknet.py:94-97).  The activation tensor of such a layer is never written: forward stores
+// only the pooled maxima; backward re-derives the four activations of each window from the fp32 conv output,
+// finds the argmax again (first maximum in row-major window order, values rounded to T exactly as the separate
+// bn -> maxpool pair sees them) and routes the pooled gradient there, so neither the activation nor its
+// gradient ever touch HBM.  x: (B,H,W,C) TX; pooled tensors (B,H/2,W/2,C) T.  One work item = one pooled granule.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void round_as(float* v) {
+  if constexpr (Granule<T>::N == 8) {       // bf16: through the storage format and back
+    const u32x4_t q = f32_to_granule<T>(v);
+    granule_to_f32<T>(q, v);
+  }
+}
+
+struct PoolWin {
+  int cg;
+  long long g00;      // input granule index of the window's top-left pixel
+  long long row;      // input granules per image row (W * cgs)
+  int cgs;
+};
+__device__ __forceinline__ PoolWin pool_window(int item, int H, int W, int cgs) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  PoolWin w;
+  w.cg = item % cgs;
+  int r = item / cgs;
+  const int ox = r % Wo; r /= Wo;
+  const int oy = r % Ho;
+  const int b = r / Ho;
+  w.cgs = cgs;
+  w.row = (long long)W * cgs;
+  w.g00 = ((long long)(b * H + oy * 2) * W + ox * 2) * cgs + w.cg;
+  return w;
+}
+__device__ __forceinline__ long long pool_tap(const PoolWin& w, int k) {
+  return w.g00 + (k >> 1) * w.row + (k & 1) * w.cgs;
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void bn_pool_fwd_kernel(
+    const TX* __restrict__ x, T* __restrict__ y, int items, int H, int W, int C, float inv_rows,
+    const float* __restrict__ sum, const float* __restrict__ sumsq, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float unbias,
+    float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float sc[EG], sh[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    const float m = sum[c] * inv_rows;
+    float var = sumsq[c] * inv_rows - m * m;
+    var = fmaxf(var, 0.f);
+    bn_scale_shift(m, rsqrtf(var + eps), gamma[c], beta[c], sc[e], sh[e]);
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      const float m = sum[c] * inv_rows;
+      float var = fmaxf(sumsq[c] * inv_rows - m * m, 0.f);
+      if (save_mean) save_mean[c] = m;
+      if (save_invstd) save_invstd[c] = rsqrtf(var + eps);
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
+    }
+  }
+  u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+  for (int item = blockIdx.x * kThreads + threadIdx.x; item < items; item += gridDim.x * kThreads) {
+    const PoolWin w = pool_window(item, H, W, cgs);
+    float v[4][EG];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_x<TX, EG>(x, pool_tap(w, k), v[k]);
+    float best[EG];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int e = 0; e < EG; ++e) v[k][e] = bn_act(v[k][e], sc[e], sh[e], act);
+      round_as<T>(v[k]);
+#pragma unroll
+      for (int e = 0; e < EG; ++e) best[e] = (k == 0 || v[k][e] > best[e]) ? v[k][e] : best[e];
+    }
+    yg[item] = f32_to_granule<T>(best);
+  }
+}
+
+// the window's activations again (forward formula, forward rounding) -> arg[e] = first maximum; xh[k][e] = xhat
+template <typename T, typename TX, int EG>
+__device__ __forceinline__ void pool_rederive(const TX* __restrict__ x, const PoolWin& w, const float* m,
+                                              const float* is, const float* sc, const float* sh, int act,
+                                              float (&xh)[4][EG], int (&arg)[EG]) {
+  float best[EG];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) load_x<TX, EG>(x, pool_tap(w, k), xh[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a[EG];
+#pragma unroll
+    for (int e = 0; e < EG; ++e) a[e] = bn_act(xh[k][e], sc[e], sh[e], act);
+    round_as<T>(a);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      if (k == 0 || a[e] > best[e]) { best[e] = a[e]; arg[e] = k; }
+      xh[k][e] = (xh[k][e] - m[e]) * is[e];
+    }
+  }
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void bn_pool_bwd_reduce_kernel(
+    const TX* __restrict__ x, const T* __restrict__ dy, int items, int H, int W, int C,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat, int replicas) {
+  constexpr int EG = Granule<T>::N;
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float m[EG], is[EG], ga[EG], be[EG], sc[EG], sh[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+    bn_scale_shift(m[e], is[e], ga[e], be[e], sc[e], sh[e]);
+  }
+  float acc[2][EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dy);
+  for (int item = blockIdx.x * kThreads + threadIdx.x; item < items; item += gridDim.x * kThreads) {
+    const PoolWin w = pool_window(item, H, W, cgs);
+    float xh[4][EG], dv[EG];
+    int arg[EG];
+    granule_to_f32<T>(dg[item], dv);
+    pool_rederive<T, TX, EG>(x, w, m, is, sc, sh, act, xh, arg);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const float xa = arg[e] == 0 ? xh[0][e] : arg[e] == 1 ? xh[1][e] : arg[e] == 2 ? xh[2][e] : xh[3][e];
+      const float pre = xa * ga[e] + be[e];
+      float d = dv[e];
+      if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+      else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+      acc[0][e] += d;
+      acc[1][e] += d * xa;
+    }
+  }
+  float* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG>(acc, C, cg, outs, replicas);
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void bn_pool_bwd_apply_kernel(
+    const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int items, int H, int W, int C,
+    float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* dgamma, float* dbeta,
+    int replicas) {
+  constexpr int EG = Granule<T>::N;
+  extern __shared__ float tot[];             // 2 * C
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float m[EG], is[EG], ga[EG], be[EG], sc[EG], sh[EG], k1[EG], k2[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+    bn_scale_shift(m[e], is[e], ga[e], be[e], sc[e], sh[e]);
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
+    const float* __restrict__ src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
+    float t = src[0];
+    for (int r = 1; r < replicas; ++r) t += src[(size_t)r * C];
+    tot[i] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    k1[e] = tot[c] * inv_rows;
+    k2[e] = tot[C + c] * inv_rows;
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      if (dgamma) dgamma[c] += tot[C + c];
+      if (dbeta) dbeta[c] += tot[c];
+    }
+  }
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dy);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+  for (int item = blockIdx.x * kThreads + threadIdx.x; item < items; item += gridDim.x * kThreads) {
+    const PoolWin w = pool_window(item, H, W, cgs);
+    float xh[4][EG], dv[EG];
+    int arg[EG];
+    granule_to_f32<T>(dg[item], dv);
+    pool_rederive<T, TX, EG>(x, w, m, is, sc, sh, act, xh, arg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o[EG];
+#pragma unroll
+      for (int e = 0; e < EG; ++e) {
+        const float pre = xh[k][e] * ga[e] + be[e];
+        float d = arg[e] == k ? dv[e] : 0.f;
+        if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+        else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+        o[e] = ga[e] * is[e] * (d - k1[e] - xh[k][e] * k2[e]);
+      }
+      og[pool_tap(w, k)] = f32_to_granule<T>(o);
+    }
   }
 }
 
@@ -491,6 +707,146 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
     float* o = gsum + (sb + threadIdx.x) * 2;
     atomicAdd(o, s_a[threadIdx.x]);
     atomicAdd(o + 1, s_b[threadIdx.x]);
+  }
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    if (dbeta) atomicAdd(dbeta + c, red[c]);
+    if (dgamma) atomicAdd(dgamma + c, red[C + c]);
+  }
+}
+
+// Spin limit of the in-kernel barriers below (~0.3 s): a barrier that cannot complete gives up, counts itself in
+// g_barrier_timeouts (kd6d_barrier_timeouts()) and lets the kernel drain -- wrong numbers instead of a hung GPU.
+__device__ unsigned int g_barrier_timeouts = 0;
+constexpr unsigned kSpinLimit = 1u << 21;
+
+// Arrive at `ctr` and wait until `need` workgroups have.  What crosses workgroups here is exchanged ONLY through
+// device-scope atomics (the partial sums, the counter) and device-scope atomic loads afterwards: those are performed
+// at the memory side, beyond the per-XCD L2s, so no L2 write-back / invalidate (what an agent-scope release /
+// acquire fence costs on a multi-XCD part, for every workgroup) is needed -- waiting for the own atomics to be
+// acknowledged (workgroup-scope release = s_waitcnt) before the arrival is enough.
+__device__ __forceinline__ void group_barrier(unsigned int* ctr, unsigned need) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned it = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++it > kSpinLimit) { atomicAdd(&g_barrier_timeouts, 1u); break; }
+    }
+  }
+  __syncthreads();
+}
+
+// GN+ReLU backward in ONE pass: the workgroup keeps its row chunk (<= kGnHold granules per thread) in registers,
+// adds its partial sums to gsum, waits until the sibling workgroups of the same (level, image) -- at most
+// hw / chunk_rows of them, consecutive block ids -- have done the same, and finishes dx from the registers: x and
+// dz are read once instead of twice and the second launch goes.  Siblings are dispatched in order and the largest
+// group is far smaller than the number of resident workgroups, so the wait always ends.
+constexpr int kGnHold = 8;
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
+    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm, float eps,
+    const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* gsum, unsigned int* counters, float* dgamma, float* dbeta) {
+  constexpr int EG = Granule<T>::N;
+  __shared__ float s_a[64], s_b[64];
+  extern __shared__ float red[];  // 2*C
+  int seg, b, r_begin, r_cnt;
+  gn_chunk(gm, blockIdx.x, seg, b, r_begin, r_cnt);
+  int hw = 1;
+#pragma unroll
+  for (int s = 0; s < KD6D_MAX_SEG; ++s)
+    if (s == seg) hw = gm.hw[s];
+  const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
+  const float inv_n = 1.f / ((float)hw * (float)cpg);
+  if (threadIdx.x < 64) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) red[i] = 0.f;
+  __syncthreads();
+  const int cg = threadIdx.x % cgs;
+  const size_t sb = (size_t)(seg * gm.batch + b) * G;
+  float ga[EG], be[EG], mu[EG], rs[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    ga[e] = gamma[c]; be[e] = beta[c];
+    gn_mean_rstd(stats + (sb + c / cpg) * 2, inv_n, eps, mu[e], rs[e]);
+  }
+  float a_dy[EG], a_dyx[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { a_dy[e] = 0.f; a_dyx[e] = 0.f; }
+  const size_t base = (size_t)r_begin * C;
+  const TX* xb = x + base;
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz + base);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx + base);
+  const int ngran = r_cnt * cgs;
+  float hd[kGnHold][EG], hx[kGnHold][EG];     // masked dz, xhat
+  // straight-line loads (index clamped, contribution masked): all of a thread's granules are in flight at once
+#pragma unroll
+  for (int i = 0; i < kGnHold; ++i) {
+    const int g = threadIdx.x + i * kThreads;
+    const bool valid = g < ngran;
+    const int gi = valid ? g : ngran - 1;
+    float xv[EG], dv[EG];
+    load_x<TX, EG>(xb, gi, xv);
+    granule_to_f32<T>(dg[gi], dv);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      const float pre = xh * ga[e] + be[e];
+      const float d = (valid && pre > 0.f) ? dv[e] : 0.f;
+      hd[i][e] = d; hx[i][e] = xh;
+      a_dy[e] += d;
+      a_dyx[e] += d * xh;
+    }
+  }
+  const bool fold = (cgs == 16 || cgs == 32);
+  if (fold) {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      a_dy[e] += __shfl_xor(a_dy[e], 32, 64);
+      a_dyx[e] += __shfl_xor(a_dyx[e], 32, 64);
+      if (cgs == 16) {
+        a_dy[e] += __shfl_xor(a_dy[e], 16, 64);
+        a_dyx[e] += __shfl_xor(a_dyx[e], 16, 64);
+      }
+    }
+  }
+  if (!fold || (int)(threadIdx.x & 63) < cgs) {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int c = cg * EG + e;
+      atomicAdd(&red[c], a_dy[e]);
+      atomicAdd(&red[C + c], a_dyx[e]);
+      atomicAdd(&s_a[c / cpg], a_dy[e] * ga[e]);
+      atomicAdd(&s_b[c / cpg], a_dyx[e] * ga[e]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float* o = gsum + (sb + threadIdx.x) * 2;
+    atomicAdd(o, s_a[threadIdx.x]);
+    atomicAdd(o + 1, s_b[threadIdx.x]);
+  }
+  // (the dgamma / dbeta atomics -- every workgroup of the launch on the same C addresses -- wait until the end:
+  //  the siblings do not need them and the barrier would otherwise sit behind that queue)
+  group_barrier(counters + seg * gm.batch + b, (unsigned)((hw + gm.chunk_rows - 1) / gm.chunk_rows));
+  float k1[EG], k2[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const float* o = gsum + (sb + (cg * EG + e) / cpg) * 2;
+    k1[e] = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_n;
+    k2[e] = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_n;
+  }
+#pragma unroll
+  for (int i = 0; i < kGnHold; ++i) {
+    const int g = threadIdx.x + i * kThreads;
+    if (g < ngran) {
+      float o[EG];
+#pragma unroll
+      for (int e = 0; e < EG; ++e) o[e] = rs[e] * (hd[i][e] * ga[e] - k1[e] - hx[i][e] * k2[e]);
+      og[g] = f32_to_granule<T>(o);
+    }
   }
   for (int c = threadIdx.x; c < C; c += kThreads) {
     if (dbeta) atomicAdd(dbeta + c, red[c]);
@@ -752,10 +1108,10 @@ int check_channels(int dtype, int C, const char* who) {
   return KD6D_OK;
 }
 
-bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom* gm) {
+bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom* gm, int chunk_rows = 0) {
   if (nseg < 1 || nseg > KD6D_MAX_SEG || batch < 1 || G < 1 || G > 64 || C % G) return false;
   gm->nseg = nseg; gm->batch = batch; gm->C = C; gm->G = G;
-  gm->chunk_rows = gn_chunk_rows();
+  gm->chunk_rows = chunk_rows > 0 ? chunk_rows : gn_chunk_rows();
   int row = 0, blk = 0;
   for (int s = 0; s < KD6D_MAX_SEG; ++s) {
     gm->row0[s] = row;
@@ -772,6 +1128,9 @@ bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom*
   gm->nblk = blk;
   return true;
 }
+
+// KD6D_GN_ONEPASS=0: the two-launch GN backward (reduce, apply); read per call
+bool gn_onepass() { const char* e = getenv("KD6D_GN_ONEPASS"); return !(e && e[0] == '0'); }
 
 long long gn_rows(const GnGeom& gm) {
   long long r = 0;
@@ -885,6 +1244,73 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, cons
   return KD6D_OK;
 }
 
+extern "C" int kd6d_barrier_timeouts(void) {
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_barrier_timeouts), sizeof(v)) != hipSuccess) return -1;
+  return (int)v;
+}
+
+static int check_pool(int dtype, int B, int H, int W, int C, const char* who, long long* items) {
+  int rc = check_channels(dtype, C, who);
+  if (rc) return rc;
+  KD6D_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "%s: B=%d H=%d W=%d (H, W must be even)", who, B, H, W);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  *items = (long long)B * (H / 2) * (W / 2) * (C / eg);
+  KD6D_CHECK_ARG(*items * 4 < (1ll << 31), "%s: %lld granules exceed the 32-bit item index", who, *items * 4);
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_bn_pool_train_fwd(int dtype, int x_f32, const void* x, void* y, int B, int H, int W, int C,
+                                      const float* sum, const float* sumsq, const float* gamma,
+                                      const float* beta, float eps, float momentum, float* running_mean,
+                                      float* running_var, float* save_mean, float* save_invstd, int act,
+                                      void* stream) {
+  long long items = 0;
+  int rc = check_pool(dtype, B, H, W, C, "kd6d_bn_pool_train_fwd", &items);
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && y && sum && sumsq && gamma && beta, "kd6d_bn_pool_train_fwd: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long rows = (long long)B * H * W;
+  const float inv_rows = 1.f / (float)rows;
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  const int nb = grid_for(items);
+  DISPATCH_TTX(dtype, x_f32,
+               hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x,
+                                   (T_*)y, (int)items, H, W, C, inv_rows, sum, sumsq, gamma, beta, eps, momentum,
+                                   unbias, running_mean, running_var, save_mean, save_invstd, act));
+  KD6D_CHECK_LAUNCH("kd6d_bn_pool_train_fwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, void* dx, int B, int H,
+                                      int W, int C, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, int act, float* sum_dy, float* sum_dy_xhat,
+                                      float* dgamma, float* dbeta, int replicas, void* stream) {
+  long long items = 0;
+  int rc = check_pool(dtype, B, H, W, C, "kd6d_bn_pool_train_bwd", &items);
+  if (rc) return rc;
+  KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_pool_train_bwd: replicas=%d outside [1,64]", replicas);
+  KD6D_CHECK_ARG(x && dy && dx && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat,
+                 "kd6d_bn_pool_train_bwd: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float inv_rows = 1.f / (float)((long long)B * H * W);
+  long long nbr = (items + kThreads * 2 - 1) / (kThreads * 2);      // 8 input granules per thread, as the unpooled pass
+  if (nbr > kBnBwdReduceCap) nbr = kBnBwdReduceCap;
+  if (nbr < 1) nbr = 1;
+  const int nba = grid_for(items);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  DISPATCH_TTX(dtype, x_f32, {
+    hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T_, TX_>), dim3((int)nbr), dim3(kThreads), lds, st,
+                       (const TX_*)x, (const T_*)dy, (int)items, H, W, C, mean, invstd, gamma, beta, act, sum_dy,
+                       sum_dy_xhat, replicas);
+    hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T_, TX_>), dim3(nba), dim3(kThreads), lds, st, (const TX_*)x,
+                       (const T_*)dy, (T_*)dx, (int)items, H, W, C, inv_rows, mean, invstd, gamma, beta, act,
+                       sum_dy, sum_dy_xhat, dgamma, dbeta, replicas);
+  });
+  KD6D_CHECK_LAUNCH("kd6d_bn_pool_train_bwd");
+  return KD6D_OK;
+}
+
 extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host,
                                 int nseg, int batch, int C, int groups, const float* gamma,
                                 const float* beta, float eps, float* stats, int flags, void* stream) {
@@ -935,6 +1361,26 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
       hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
     kd6d_set_error("kd6d_gn_relu_bwd: memset failed");
     return KD6D_ERR_LAUNCH;
+  }
+  if (gn_onepass()) {
+    // row chunks small enough for the registers of one workgroup; the barrier counters sit behind the sums
+    const int cgs = C / eg;
+    int chunk = gn_chunk_rows();
+    if (chunk * cgs > kGnHold * kThreads) chunk = kGnHold * kThreads / cgs;
+    GnGeom g1;
+    KD6D_CHECK_ARG(chunk >= 1 && fill_gn(level_hw_host, nseg, batch, C, groups, &g1, chunk), "kd6d_gn_relu_bwd: geometry");
+    unsigned int* counters = reinterpret_cast<unsigned int*>(gsum_ws + 2 * (size_t)nseg * batch * groups);
+    if (!(flags & KD6D_GN_WS_ZEROED) &&
+        hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)nseg * batch, st) != hipSuccess) {
+      kd6d_set_error("kd6d_gn_relu_bwd: memset failed");
+      return KD6D_ERR_LAUNCH;
+    }
+    DISPATCH_TTX(dtype, x_f32,
+                 hipLaunchKernelGGL((gn_relu_bwd_onepass_kernel<T_, TX_>), dim3(g1.nblk), dim3(kThreads), lds, st,
+                                    (const TX_*)x, (const T_*)dz, (T_*)dx, g1, eps, stats, gamma, beta, gsum_ws,
+                                    counters, dgamma, dbeta));
+    KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd");
+    return KD6D_OK;
   }
   DISPATCH_TTX(dtype, x_f32, {
     hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<T_, TX_>), dim3(gm.nblk), dim3(kThreads), lds, st,

@@ -15,7 +15,7 @@ KD6D_F32 = 1
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 GN_STATS_READY, GN_WS_ZEROED = 1, 2
 MAX_SEG = 5
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Seg(ctypes.Structure):
@@ -61,6 +61,9 @@ SIGNATURES = {
     "kd6d_bn_train_fwd": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     "kd6d_bn_train_bwd_reduce": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "kd6d_bn_train_bwd_apply": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "kd6d_barrier_timeouts": [],
+    "kd6d_bn_pool_train_fwd": [_I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
+    "kd6d_bn_pool_train_bwd": [_I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P,
                          _P, _P, _P, _I, _P],

@@ -11,6 +11,7 @@ models/model.py:40-103 (FPN), :370-451 (PoseHead).  Parameter NAMES and logical 
 reference state_dict; storage is KRSC with channels padded to multiples of 8.
 """
 import math
+import os
 
 import torch
 
@@ -242,7 +243,9 @@ class ConvBlock:
         y, g = self.conv.fwd(x, batch, levels, scale=sc, shift=sh, act=ACT_LEAKY, residual=residual)
         return y, g.levels_out
 
-    def fwd_train(self, x, batch, levels, tape):
+    def fwd_train(self, x, batch, levels, tape, pool=False):
+        """pool=True: the block is followed by MaxPool2d(2,2) (darknet.py:94-97); normalisation, activation and
+        pooling run as one kernel and only the pooled tensor is stored (csrc/norm_ops.hip, bn_pool_*)."""
         net, st = self.net, self.net.store
         # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
         c = self.conv.cout_p
@@ -257,14 +260,21 @@ class ConvBlock:
                                stats=s[0:2 * c] if fused else None, stats_groups=0)
         if not fused:
             ops.colstats(raw, ssum, ssq)
+        if pool:
+            (h, w), = g.levels_out
+            z = net.buf(self.name + ".zpool", (batch * (h // 2) * (w // 2), c), net.dtype)
+            ops.bn_pool_train_fwd(raw, z, batch, h, w, ssum, ssq, st.storage(self.bn.gamma), st.storage(self.bn.beta),
+                                  1e-5, 0.1, st.storage(self.bn.rm), st.storage(self.bn.rv), mean, invstd, ACT_LEAKY)
+            tape.append((self, x, raw, batch, tuple(levels), (h, w)))
+            return z, [(h // 2, w // 2)]
         z = net.buf(self.name + ".z", raw.shape, net.dtype)
         ops.bn_train_fwd(raw, z, ssum, ssq, st.storage(self.bn.gamma), st.storage(self.bn.beta), 1e-5, 0.1,
                          st.storage(self.bn.rm), st.storage(self.bn.rv), mean, invstd, ACT_LEAKY)
-        tape.append((self, x, raw, batch, tuple(levels)))
+        tape.append((self, x, raw, batch, tuple(levels), None))
         return z, g.levels_out
 
     def bwd(self, rec, dz, need_dx=True, dx=None, accumulate=False):
-        _, x, raw, batch, levels = rec
+        _, x, raw, batch, levels, pooled = rec
         net, st = self.net, self.net.store
         c = self.conv.cout_p
         R = self.bwd_replicas(raw.shape[0])
@@ -272,9 +282,14 @@ class ConvBlock:
         mean, invstd = s[2 * c:3 * c], s[3 * c:4 * c]
         w1, w2 = s[4 * c:(4 + R) * c], s[(4 + R) * c:(4 + 2 * R) * c]
         draw = net.buf(self.name + ".draw", raw.shape, net.dtype)
-        ops.bn_train_bwd(raw, dz, draw, mean, invstd, st.storage(self.bn.gamma), st.storage(self.bn.beta),
-                         ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"), st.storage(self.bn.beta, "grads"),
-                         replicas=R)
+        if pooled is not None:                  # dz is the gradient of the pooled output
+            ops.bn_pool_train_bwd(raw, dz, draw, batch, pooled[0], pooled[1], mean, invstd, st.storage(self.bn.gamma),
+                                  st.storage(self.bn.beta), ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"),
+                                  st.storage(self.bn.beta, "grads"), replicas=R)
+        else:
+            ops.bn_train_bwd(raw, dz, draw, mean, invstd, st.storage(self.bn.gamma), st.storage(self.bn.beta),
+                             ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"), st.storage(self.bn.beta, "grads"),
+                             replicas=R)
         return self.conv.bwd(x, draw, batch, levels, need_dx=need_dx, dx=dx, accumulate=accumulate)
 
 
@@ -303,7 +318,7 @@ class GroupNormReLU:
         net, st = self.net, self.net.store
         hw = [h * w for (h, w) in levels]
         stats = self.stats(batch, levels)
-        gsum = net.scratch(self.name + ".gsum", stats.numel())
+        gsum = net.scratch(self.name + ".gsum", ops.gn_bwd_workspace_floats(len(levels), batch, self.groups))
         ops.gn_relu_bwd(x, dz, dx, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), stats,
                         gsum, st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"),
                         flags=ops.GN_WS_ZEROED)
@@ -327,6 +342,7 @@ class PoseNet:
         self.side_stream = None        # set (e.g. by GraphedKDStep) to run weight gradients concurrently
         self.side_streams = None       # optional list: consecutive weight gradients rotate over these streams
         self.wgrad_cu_budget = 0       # CUs each forked weight gradient aims to fill (0 = the device)
+        self.fuse_pool = os.environ.get("KD6D_FUSE_POOL", "1") != "0"   # BN + act + maxpool as one kernel (training)
         self._side_rr = 0
         feat, oc = BACKBONE_CFG[arch]
         self.out_channel = oc
@@ -530,6 +546,13 @@ class PoseNet:
         feats = []
         n = len(self.stages)
         for i, units in enumerate(self.stages):
+            if self.training and self.fuse_pool:
+                for j, u in enumerate(units):
+                    x, lv = u.fwd_train(x, B, lv, self.tape, pool=(i != n - 1 and j == len(units) - 1))
+                if i != n - 1:
+                    self.tape.append(("pooled", i))
+                feats.append((x, lv))
+                continue
             for u in units:
                 x, lv = u.fwd_train(x, B, lv, self.tape) if self.training else u.fwd_eval(x, B, lv)
             if i != n - 1:
@@ -678,7 +701,10 @@ class PoseNet:
         n_pools = sum(1 for t in self.tape if t[0] == "pool")
         while i_rec >= 0:
             rec = self.tape[i_rec]
-            if rec[0] == "pool":
+            if rec[0] == "pooled":              # the pool lives inside the block's BN kernels; out3 = after pool 2
+                if rec[1] == 2 and pending[2] is not None:
+                    grad = ops.eltwise(ops.ELT_ADD, grad, pending[2], self.buf("d_out3", grad.shape))
+            elif rec[0] == "pool":
                 _, x, b_, h, w = rec
                 pool_idx = n_pools - 1 - pools_seen    # 3,2,1,0
                 pools_seen += 1

@@ -216,6 +216,31 @@ def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy
     return dx
 
 
+def bn_pool_train_fwd(x, y, batch, h, w, sum_, sumsq, gamma, beta, eps, momentum, running_mean, running_var,
+                      save_mean, save_invstd, act):
+    """BN(train) + act + MaxPool2d(2,2): x (batch*h*w, C) conv output -> y (batch*h/2*w/2, C) pooled."""
+    rows, c = x.shape
+    assert rows == batch * h * w and tuple(y.shape) == (batch * (h // 2) * (w // 2), c)
+    check(lib.kd6d_bn_pool_train_fwd(dt_code(y.dtype), _xf32(x, y.dtype), _ptr(x), _ptr(y), batch, h, w, c,
+                                     _ptr(sum_), _ptr(sumsq), _ptr(gamma), _ptr(beta), eps, momentum,
+                                     _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), act,
+                                     _stream()), "kd6d_bn_pool_train_fwd")
+    return y
+
+
+def bn_pool_train_bwd(x, dy, dx, batch, h, w, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma,
+                      dbeta, replicas=1):
+    """dy: gradient of the POOLED output; dx: gradient of the conv output x (same rows as x, dtype of dy)."""
+    rows, c = x.shape
+    assert rows == batch * h * w and tuple(dy.shape) == (batch * (h // 2) * (w // 2), c) and dx.shape == x.shape
+    assert ws_sum_dy.numel() >= replicas * c and ws_sum_dy_xhat.numel() >= replicas * c
+    check(lib.kd6d_bn_pool_train_bwd(dt_code(dy.dtype), _xf32(x, dy.dtype), _ptr(x), _ptr(dy), _ptr(dx), batch, h, w,
+                                     c, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
+                                     _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), replicas, _stream()),
+          "kd6d_bn_pool_train_bwd")
+    return dx
+
+
 def _hw_array(level_hw):
     arr = (ctypes.c_int32 * len(level_hw))(*[int(v) for v in level_hw])
     return arr
@@ -231,9 +256,15 @@ def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats, flags=0)
     return y
 
 
+def gn_bwd_workspace_floats(n_levels, batch, groups):
+    """Floats of kd6d_gn_relu_bwd's workspace: the group sums plus one barrier counter per (level, image)."""
+    return 2 * n_levels * batch * groups + n_levels * batch
+
+
 def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta, eps=1e-5, flags=0):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
+    assert gsum_ws.numel() >= gn_bwd_workspace_floats(len(level_hw), batch, groups), "gsum_ws too small (kd6d.h)"
     check(lib.kd6d_gn_relu_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
                                len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats),
                                _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), flags, _stream()), "kd6d_gn_relu_bwd")

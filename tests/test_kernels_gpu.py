@@ -367,6 +367,73 @@ def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows):
     torch.testing.assert_close(dbet.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * gs)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,xf32", [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 16, 16, 64), (2, 64, 64, 16), (16, 64, 64, 8), (1, 2, 2, 256)])
+def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H, W, C):
+    """BN(train)+LeakyReLU+MaxPool2d(2,2) as one kernel (darknet.py:94-97 behind a ConvBlock): the pooled output is
+    bit-identical to bn_train_fwd -> maxpool2_fwd, the backward matches bn_train_bwd(maxpool2_bwd(.)) up to the
+    order of the fp32 reductions, and both agree with torch autograd in float64.  Ties inside a window (common in
+    bf16) exercise the first-maximum rule."""
+    ops = _ops()
+    dev = gpu_device
+    if dtype == torch.float32 and C % 4:
+        pytest.skip("granule")
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + C)
+    rows = B * H * W
+    xt = torch.float32 if xf32 else dtype
+    x = torch.randn(rows, C, generator=g) * 2 + 0.5
+    n_tie = x[1::3].shape[0]
+    x[::3][:n_tie] = x[1::3]                     # equal neighbours -> ties inside windows
+    x = round_to(x, xt)
+    dy = round_to(torch.randn(B * (H // 2) * (W // 2), C, generator=g), dtype)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    xd, dyd = x.to(xt).to(dev), dy.to(dtype).to(dev)
+    s1 = torch.zeros(C, device=dev); s2 = torch.zeros(C, device=dev)
+    ops.colstats(xd, s1, s2)
+    R = 1 if rows < 1000 else 8
+
+    def run(fused):
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
+        w1 = torch.zeros(R * C, device=dev); w2 = torch.zeros(R * C, device=dev)
+        dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
+        yp = torch.empty_like(dyd)
+        dx = torch.empty(rows, C, dtype=dtype, device=dev)
+        if fused:
+            ops.bn_pool_train_fwd(xd, yp, B, H, W, s1, s2, gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
+            ops.bn_pool_train_bwd(xd, dyd, dx, B, H, W, mean, invstd, gamma, beta, 1, w1, w2, dgam, dbet, replicas=R)
+        else:
+            z = torch.empty(rows, C, dtype=dtype, device=dev)
+            ops.bn_train_fwd(xd, z, s1, s2, gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
+            ops.maxpool2_fwd(z, yp, B, H, W)
+            dz = torch.empty_like(z)
+            ops.maxpool2_bwd(z, dyd, dz, B, H, W)
+            ops.bn_train_bwd(xd, dz, dx, mean, invstd, gamma, beta, 1, w1, w2, dgam, dbet, replicas=R)
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (yp, dx, dgam, dbet, rm, rv)]
+
+    fy, fdx, fdg, fdb, frm, frv = run(True)
+    uy, udx, udg, udb, urm, urv = run(False)
+    assert torch.equal(fy, uy)
+    assert torch.equal(frm, urm) and torch.equal(frv, urv)
+    tol = _tol(dtype, stored=True)
+    torch.testing.assert_close(fdx.double(), udx.double(), **tol)
+    gs = max(1.0, float(udg.abs().max()))
+    torch.testing.assert_close(fdg, udg, rtol=1e-4, atol=1e-4 * gs)
+    torch.testing.assert_close(fdb, udb, rtol=1e-4, atol=1e-4 * gs)
+    if dtype == torch.float32:                  # float64 autograd (no ties to speak of after fp32 rounding)
+        xr = x.double().requires_grad_(True)
+        gr, br = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True)
+        a = F.leaky_relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5), 0.1)
+        p = F.max_pool2d(a.view(B, H, W, C).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(-1, C)
+        p.backward(dy.double())
+        torch.testing.assert_close(fy.double(), p.detach(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(fdx.double(), xr.grad, rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(fdg.double(), gr.grad, rtol=1e-3, atol=1e-3 * gs)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,rows", [(240, 1003), (16, 50), (40, 333)])
 def test_colstats_any_channel_count(gpu_device, dtype, C, rows):
@@ -382,10 +449,15 @@ def test_colstats_any_channel_count(gpu_device, dtype, C, rows):
 
 @pytest.mark.parametrize("dtype,xf32", MIXED)
 @pytest.mark.parametrize("C", [128, 256])
-def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C):
+@pytest.mark.parametrize("levels,onepass", [([(6, 6), (3, 3), (2, 2), (1, 1)], "1"), ([(6, 6), (3, 3), (2, 2), (1, 1)], "0"),
+                                            ([(32, 32), (16, 12), (5, 5)], "1"), ([(32, 32), (16, 12), (5, 5)], "0")])
+def test_groupnorm_relu_fwd_bwd(gpu_device, monkeypatch, dtype, xf32, C, levels, onepass):
+    """onepass "1": the backward is one kernel whose workgroups of a (level, image) meet at an in-kernel barrier
+    (32x32 levels span 8..32 workgroups); "0": the reduce + apply pair."""
     ops = _ops()
     dev = gpu_device
-    B, G, levels = 3, 32, [(6, 6), (3, 3), (2, 2), (1, 1)]
+    monkeypatch.setenv("KD6D_GN_ONEPASS", onepass)
+    B, G = 3, 32
     g = torch.Generator().manual_seed(C)
     xdt = torch.float32 if xf32 else dtype
     xs = [round_to(torch.randn(B, C, h, w, generator=g) * 1.5 + 0.2, xdt) for (h, w) in levels]
@@ -404,11 +476,12 @@ def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C):
     xp = pack_levels(xs, xdt).to(dev); dzp = pack_levels(dzs, dtype).to(dev)
     y = torch.empty_like(dzp); dx = torch.empty_like(dzp)
     stats = torch.empty(len(levels) * B * G * 2, device=dev)
-    gsum = torch.empty_like(stats)
+    gsum = torch.empty(ops.gn_bwd_workspace_floats(len(levels), B, G), device=dev)
     dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
     ops.gn_relu_fwd(xp, y, hw, B, G, gamma.to(dev), beta.to(dev), 1e-5, stats)     # flags=0: reduces + zeroes itself
     ops.gn_relu_bwd(xp, dzp, dx, hw, B, G, gamma.to(dev), beta.to(dev), stats, gsum, dgam, dbet)
     torch.cuda.synchronize()
+    assert ops.lib.kd6d_barrier_timeouts() == 0
     tol = _tol(dtype, stored=True)
     for gl, ref in zip(unpack_levels(y.cpu(), B, levels), refs):
         torch.testing.assert_close(gl.double(), ref, **tol)

@@ -74,6 +74,41 @@ def main():
         row(name, "bn_bwd_reduce", rows, c, mb_x + mb_a, timeit_graph(reduce_only, a.iters))
         row(name, "bn_bwd_apply", rows, c, mb_x + 2 * mb_a, timeit_graph(apply_only, a.iters))
 
+    # the four ConvBlocks that sit in front of a MaxPool2d(2,2): fused BN + act + pool against the separate launches
+    for name, side, c in [("u1", 256, 8), ("u2", 128, 16), ("s3.last", 64, 64), ("s4.last", 32, 128)]:
+        rows = B * side * side
+        x = torch.randn(rows, c, device=dev)
+        z = torch.empty(rows, c, dtype=bf, device=dev)
+        dz = torch.empty(rows, c, dtype=bf, device=dev)
+        yp = torch.empty(rows // 4, c, dtype=bf, device=dev)
+        dyp = torch.randn(rows // 4, c, device=dev).to(bf)
+        dx = torch.empty(rows, c, dtype=bf, device=dev)
+        R = 8 if rows >= (1 << 14) else 1
+        s = torch.zeros((4 + 2 * R) * c, device=dev)
+        gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        ops.colstats(x, s[0:c], s[c:2 * c])
+        mean, invstd, w1, w2 = s[2 * c:3 * c], s[3 * c:4 * c], s[4 * c:(4 + R) * c], s[(4 + R) * c:]
+        mb_x, mb_a = rows * c * 4 / 1e6, rows * c * 2 / 1e6
+
+        def fwd_sep():
+            ops.bn_train_fwd(x, z, s[0:c], s[c:2 * c], gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
+            ops.maxpool2_fwd(z, yp, B, side, side)
+
+        def bwd_sep():
+            ops.maxpool2_bwd(z, dyp, dz, B, side, side)
+            ops.bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, 1, w1, w2, dg, db, replicas=R)
+
+        row(name, "bn_apply + maxpool (2 launches)", rows, c, mb_x + 2.25 * mb_a, timeit_graph(fwd_sep, a.iters))
+        row(name, "bn_pool_fwd (fused)", rows, c, mb_x + 0.25 * mb_a, timeit_graph(
+            lambda: ops.bn_pool_train_fwd(x, yp, B, side, side, s[0:c], s[c:2 * c], gamma, beta, 1e-5, 0.1, rm, rv,
+                                          mean, invstd, 1), a.iters))
+        row(name, "maxpool_bwd + bn_bwd (3 launches)", rows, c, 2 * mb_x + 5.25 * mb_a, timeit_graph(bwd_sep, a.iters))
+        row(name, "bn_pool_bwd (fused, 2 launches)", rows, c, 2 * mb_x + 1.5 * mb_a, timeit_graph(
+            lambda: ops.bn_pool_train_bwd(x, dyp, dx, B, side, side, mean, invstd, gamma, beta, 1, w1, w2, dg, db,
+                                          replicas=R), a.iters))
+
     c, groups = 128, 32
     rows = B * sum(GN_LEVELS)
     x = torch.randn(rows, c, device=dev)
@@ -83,7 +118,7 @@ def main():
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
     stats = torch.zeros(len(GN_LEVELS) * B * groups * 2, device=dev)
-    gsum = torch.zeros_like(stats)
+    gsum = torch.zeros(ops.gn_bwd_workspace_floats(len(GN_LEVELS), B, groups), device=dev)
     ops.gn_relu_fwd(x, y, GN_LEVELS, B, groups, gamma, beta, 1e-5, stats)
     mb_x, mb_a = rows * c * 4 / 1e6, rows * c * 2 / 1e6
     row("head", "gn_fwd (stats ready)", rows, c, mb_x + mb_a, timeit_graph(
