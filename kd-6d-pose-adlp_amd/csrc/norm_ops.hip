@@ -23,9 +23,18 @@ __device__ __forceinline__ float row_ror_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + O, 0xF, 0xF, true));
 }
 
+// Device-scope float add whose RESULT the thread waits for: the value can only come back from where the add was
+// performed, so once it is here the add is visible to every later device-scope access of any workgroup.  The
+// kernels with an in-kernel barrier publish their partial sums with it (a returnless atomic is acknowledged
+// earlier than that and could be overtaken by the barrier's arrival on another memory channel).
+__device__ __forceinline__ void atomic_add_performed(float* p, float v) {
+  const float r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::"v"(r));
+}
+
 // out[a]: `replicas` rows of C floats; this workgroup adds into row blockIdx.x % replicas (the rows are summed
 // by the consumer), so an address sees 1/replicas of the serially retired atomics.
-template <int NACC, int EG>
+template <int NACC, int EG, bool PERFORMED = false>
 __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int C, int cg,
                                                     float* const* out, int replicas = 1) {
   extern __shared__ float red[];  // NACC * C floats
@@ -59,8 +68,58 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
   const int roff = replicas > 1 ? (int)(blockIdx.x % replicas) * C : 0;
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
     const int a = i / C, c = i - a * C;
-    if (out[a]) atomicAdd(out[a] + roff + c, red[i]);
+    if (out[a]) {
+      if (PERFORMED) atomic_add_performed(out[a] + roff + c, red[i]);
+      else atomicAdd(out[a] + roff + c, red[i]);
+    }
   }
+}
+
+// Spin limit of the in-kernel barriers below (~0.3 s): a barrier that cannot complete gives up, counts itself in
+// g_barrier_timeouts (kd6d_barrier_timeouts()) and lets the kernel drain -- wrong numbers instead of a hung GPU.
+__device__ unsigned int g_barrier_timeouts = 0;
+constexpr unsigned kSpinLimit = 1u << 21;
+
+// Arrive at `ctr` and wait until `need` workgroups have.  What crosses workgroups here is exchanged ONLY through
+// device-scope atomics (the partial sums, the counter) and device-scope atomic loads afterwards: those are performed
+// at the memory side, beyond the per-XCD L2s, so no L2 write-back / invalidate (what an agent-scope release /
+// acquire fence costs on a multi-XCD part, for every workgroup) is needed -- the partial sums are published with
+// atomic_add_performed (their results are back before the workgroup arrives), the workgroup-scope release and the
+// __syncthreads order the arrival behind them.
+__device__ __forceinline__ void group_barrier(unsigned int* ctr, unsigned need) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned it = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++it > kSpinLimit) { atomicAdd(&g_barrier_timeouts, 1u); break; }
+    }
+  }
+  __syncthreads();
+}
+
+// All workgroups of the launch.  512 arrivals on one word would retire one after the other (~27 ns each, 14 us):
+// they are spread over kBarrierFan sub-counters (ctr[1..]) whose last arrivers report to ctr[0], the word everyone
+// polls.  ctr: KD6D_BARRIER_WORDS pre-zeroed words.
+constexpr unsigned kBarrierFan = 16;
+__device__ __forceinline__ void grid_barrier(unsigned int* ctr, unsigned nblocks) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned sub = blockIdx.x % kBarrierFan;
+    const unsigned in_sub = (nblocks - sub + kBarrierFan - 1) / kBarrierFan;
+    const unsigned old = __hip_atomic_fetch_add(ctr + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == in_sub) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned need = nblocks < kBarrierFan ? nblocks : kBarrierFan;
+    unsigned it = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++it > kSpinLimit) { atomicAdd(&g_barrier_timeouts, 1u); break; }
+    }
+  }
+  __syncthreads();
 }
 
 // Row-tiled variant of the ownership rule: thread t owns channel granule t % cgs of row t / cgs
@@ -487,6 +546,214 @@ __global__ __launch_bounds__(kThreads) void bn_pool_bwd_apply_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// BN backward in ONE launch: every workgroup keeps its slice (<= kBnHold granules per thread, raw x and dz) in
+// registers, adds its partial sums into the replica rows, meets all other workgroups of the launch at an
+// in-kernel barrier and finishes dx from the registers -- x and dz are read once and the second launch with its
+// prologue goes.  The host only launches grids of at most 3/4 of the workgroups the device keeps resident
+// (occupancy query; the kernels are held under 170 VGPRs -> 3 workgroups per CU, 768 on an MI355X, grid <= 512)
+// and a step has one such kernel in flight at a time, so the barrier completes; group_barrier's spin limit is the
+// safety net.  Larger tensors take the reduce + apply pair.
+// ---------------------------------------------------------------------------
+constexpr int kBnHold = 4;
+constexpr int kBnOnepassBlocks = 512;
+
+// totals of the replica rows -> tot[2C] (LDS), read with device-scope atomic loads (see group_barrier)
+__device__ __forceinline__ void replica_totals(const float* sum_dy, const float* sum_dy_xhat, int C, int replicas,
+                                               float* tot) {
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
+    const float* src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
+    float t = 0.f;
+    for (int r0 = 0; r0 < replicas; r0 += 8) {           // eight loads in flight: one memory round trip, not eight
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        v[r] = r0 + r < replicas ? __hip_atomic_load(src + (size_t)(r0 + r) * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += v[r];
+    }
+    tot[i] = t;
+  }
+  __syncthreads();
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads, 3) void bn_bwd_onepass_kernel(
+    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int per_thread, int C,
+    float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat,
+    unsigned int* counter, float* dgamma, float* dbeta, int replicas) {
+  constexpr int EG = Granule<T>::N;
+  extern __shared__ float red[];             // 2 * C (block_channel_flush, then the totals)
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float m[EG], is[EG], ga[EG], be[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+  }
+  float acc[2][EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+  const long long base = (long long)blockIdx.x * per_thread * kThreads + threadIdx.x;
+  float hx[kBnHold][EG];
+  u32x4_t hz[kBnHold];
+#pragma unroll
+  for (int i = 0; i < kBnHold; ++i) {
+    const long long g = base + (long long)i * kThreads;
+    const bool valid = i < per_thread && g < ngran;
+    const long long gi = valid ? g : 0;
+    load_x<TX, EG>(x, gi, hx[i]);
+    hz[i] = dg[gi];
+    if (!valid) hz[i] = u32x4_t{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int i = 0; i < kBnHold; ++i) {
+    float dv[EG];
+    granule_to_f32<T>(hz[i], dv);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const float xh = (hx[i][e] - m[e]) * is[e];
+      const float pre = xh * ga[e] + be[e];
+      float d = dv[e];
+      if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+      else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+      acc[0][e] += d;
+      acc[1][e] += d * xh;
+    }
+  }
+  float* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG, true>(acc, C, cg, outs, replicas);
+  grid_barrier(counter, gridDim.x);
+  // only the RAW slice crosses the barrier: without this the compiler also keeps xhat and the masked gradient of
+  // the first phase alive (twice the registers, half the resident workgroups)
+#pragma unroll
+  for (int i = 0; i < kBnHold; ++i) {
+    asm volatile("" : "+v"(hz[i].x), "+v"(hz[i].y), "+v"(hz[i].z), "+v"(hz[i].w));
+#pragma unroll
+    for (int e = 0; e < EG; ++e) asm volatile("" : "+v"(hx[i][e]));
+  }
+  replica_totals(sum_dy, sum_dy_xhat, C, replicas, red);
+  float k1[EG], k2[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    k1[e] = red[c] * inv_rows;
+    k2[e] = red[C + c] * inv_rows;
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      if (dgamma) dgamma[c] += red[C + c];
+      if (dbeta) dbeta[c] += red[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kBnHold; ++i) {
+    const long long g = base + (long long)i * kThreads;
+    if (i < per_thread && g < ngran) {
+      float dv[EG];
+      granule_to_f32<T>(hz[i], dv);
+#pragma unroll
+      for (int e = 0; e < EG; ++e) {
+        const float xh = (hx[i][e] - m[e]) * is[e];
+        const float pre = xh * ga[e] + be[e];
+        float d = dv[e];
+        if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+        else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+        dv[e] = ga[e] * is[e] * (d - k1[e] - xh * k2[e]);
+      }
+      og[g] = f32_to_granule<T>(dv);
+    }
+  }
+}
+
+// the pooled variant: <= kPoolHold windows per thread (xhat of the four taps, the pooled gradient, the argmax)
+constexpr int kPoolHold = 2;
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
+    const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int items, int per_thread, int H, int W,
+    int C, float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat,
+    unsigned int* counter, float* dgamma, float* dbeta, int replicas) {
+  constexpr int EG = Granule<T>::N;
+  extern __shared__ float red[];
+  const int cgs = C / EG;
+  const int cg = threadIdx.x % cgs;
+  float m[EG], is[EG], ga[EG], be[EG], sc[EG], sh[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+    bn_scale_shift(m[e], is[e], ga[e], be[e], sc[e], sh[e]);
+  }
+  float acc[2][EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dy);
+  u32x4_t* og = reinterpret_cast<u32x4_t*>(dx);
+  const int base = blockIdx.x * per_thread * kThreads + threadIdx.x;
+  float hx[kPoolHold][4][EG];
+  float hd[kPoolHold][EG];
+  int harg[kPoolHold][EG];
+#pragma unroll
+  for (int i = 0; i < kPoolHold; ++i) {
+    const int item = base + i * kThreads;
+    const bool valid = i < per_thread && item < items;
+    const PoolWin w = pool_window(valid ? item : 0, H, W, cgs);
+    granule_to_f32<T>(dg[valid ? item : 0], hd[i]);
+    pool_rederive<T, TX, EG>(x, w, m, is, sc, sh, act, hx[i], harg[i]);
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int a = harg[i][e];
+      const float xa = a == 0 ? hx[i][0][e] : a == 1 ? hx[i][1][e] : a == 2 ? hx[i][2][e] : hx[i][3][e];
+      const float pre = xa * ga[e] + be[e];
+      float d = valid ? hd[i][e] : 0.f;
+      if (act == KD6D_ACT_LEAKY) d = pre > 0.f ? d : 0.1f * d;
+      else if (act == KD6D_ACT_RELU) d = pre > 0.f ? d : 0.f;
+      hd[i][e] = d;                           // the activation's derivative is already applied
+      acc[0][e] += d;
+      acc[1][e] += d * xa;
+    }
+  }
+  float* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG, true>(acc, C, cg, outs, replicas);
+  grid_barrier(counter, gridDim.x);
+  replica_totals(sum_dy, sum_dy_xhat, C, replicas, red);
+  float k1[EG], k2[EG];
+#pragma unroll
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    k1[e] = red[c] * inv_rows;
+    k2[e] = red[C + c] * inv_rows;
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      if (dgamma) dgamma[c] += red[C + c];
+      if (dbeta) dbeta[c] += red[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPoolHold; ++i) {
+    const int item = base + i * kThreads;
+    if (i < per_thread && item < items) {
+      const PoolWin w = pool_window(item, H, W, cgs);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float o[EG];
+#pragma unroll
+        for (int e = 0; e < EG; ++e) {
+          const float d = harg[i][e] == k ? hd[i][e] : 0.f;
+          o[e] = ga[e] * is[e] * (d - k1[e] - hx[i][k][e] * k2[e]);
+        }
+        og[pool_tap(w, k)] = f32_to_granule<T>(o);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // GroupNorm(G) + ReLU over multi-level NHWC tensors.  Statistics are kept as RAW sums
 // stats[(seg*batch + b)*G + g] = {sum x, sum x^2} (fp32 atomics from row-chunk workgroups,
 // so a 32x32 level is reduced by 16 workgroups instead of one); consumers derive
@@ -714,30 +981,6 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
   }
 }
 
-// Spin limit of the in-kernel barriers below (~0.3 s): a barrier that cannot complete gives up, counts itself in
-// g_barrier_timeouts (kd6d_barrier_timeouts()) and lets the kernel drain -- wrong numbers instead of a hung GPU.
-__device__ unsigned int g_barrier_timeouts = 0;
-constexpr unsigned kSpinLimit = 1u << 21;
-
-// Arrive at `ctr` and wait until `need` workgroups have.  What crosses workgroups here is exchanged ONLY through
-// device-scope atomics (the partial sums, the counter) and device-scope atomic loads afterwards: those are performed
-// at the memory side, beyond the per-XCD L2s, so no L2 write-back / invalidate (what an agent-scope release /
-// acquire fence costs on a multi-XCD part, for every workgroup) is needed -- waiting for the own atomics to be
-// acknowledged (workgroup-scope release = s_waitcnt) before the arrival is enough.
-__device__ __forceinline__ void group_barrier(unsigned int* ctr, unsigned need) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned it = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++it > kSpinLimit) { atomicAdd(&g_barrier_timeouts, 1u); break; }
-    }
-  }
-  __syncthreads();
-}
-
 // GN+ReLU backward in ONE pass: the workgroup keeps its row chunk (<= kGnHold granules per thread) in registers,
 // adds its partial sums to gsum, waits until the sibling workgroups of the same (level, image) -- at most
 // hw / chunk_rows of them, consecutive block ids -- have done the same, and finishes dx from the registers: x and
@@ -825,8 +1068,8 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
   __syncthreads();
   if (threadIdx.x < G) {
     float* o = gsum + (sb + threadIdx.x) * 2;
-    atomicAdd(o, s_a[threadIdx.x]);
-    atomicAdd(o + 1, s_b[threadIdx.x]);
+    atomic_add_performed(o, s_a[threadIdx.x]);
+    atomic_add_performed(o + 1, s_b[threadIdx.x]);
   }
   // (the dgamma / dbeta atomics -- every workgroup of the launch on the same C addresses -- wait until the end:
   //  the siblings do not need them and the barrier would otherwise sit behind that queue)
@@ -1129,6 +1372,36 @@ bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom*
   return true;
 }
 
+// Workgroups of `kernel` the device keeps resident at once (occupancy x CUs); 0 if the query fails.  The kernels
+// with an in-kernel barrier are only launched with grids well inside it.
+template <typename K>
+int resident_workgroups(K kernel, size_t lds) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, lds) != hipSuccess) return 0;
+  return per_cu * kd6d_device_cu_count();
+}
+template <typename T, typename TX>
+int bn_onepass_capacity(bool pooled) {
+  static const int plain = resident_workgroups(bn_bwd_onepass_kernel<T, TX>, 16384);
+  static const int pool = resident_workgroups(bn_pool_bwd_onepass_kernel<T, TX>, 16384);
+  return pooled ? pool : plain;
+}
+template <typename T, typename TX>
+int gn_onepass_capacity() {
+  static const int v = resident_workgroups(gn_relu_bwd_onepass_kernel<T, TX>, 16384);
+  return v;
+}
+// KD6D_BN_ONEPASS=0: the two-launch BN backward even when the caller passes a barrier counter; read per call
+bool bn_onepass() { const char* e = getenv("KD6D_BN_ONEPASS"); return !(e && e[0] == '0'); }
+// Largest tensor (16-B granules of x) that takes the one-launch BN backward.  Measured on an MI355X
+// (tools/bench_norm.py): up to ~128 workgroups the barrier is cheaper than a second launch (11-13 us against
+// 15 us per layer); at 256-512 workgroups publishing and collecting the partial sums through device-scope
+// returning atomics costs more than re-reading x and dz (27-29 us against 20 us), so those keep the pair.
+// KD6D_BN_ONEPASS_MAX=<granules> overrides (tests drive 512-workgroup grids through it); read per call.
+long long bn_onepass_max_granules() {
+  const char* e = getenv("KD6D_BN_ONEPASS_MAX");
+  return e ? atoll(e) : 65536;
+}
 // KD6D_GN_ONEPASS=0: the two-launch GN backward (reduce, apply); read per call
 bool gn_onepass() { const char* e = getenv("KD6D_GN_ONEPASS"); return !(e && e[0] == '0'); }
 
@@ -1244,6 +1517,43 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, cons
   return KD6D_OK;
 }
 
+extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 int act, float* sum_dy, float* sum_dy_xhat, unsigned int* counter, float* dgamma,
+                                 float* dbeta, int replicas, void* stream) {
+  int rc = check_channels(dtype, C, "kd6d_bn_train_bwd");
+  if (rc) return rc;
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  const long long ngran = rows * (C / eg);
+  int cap = 0;
+  DISPATCH_TTX(dtype, x_f32, cap = (bn_onepass_capacity<T_, TX_>(false)));
+  cap = cap * 3 / 4;                                      // the whole grid must be resident for the barrier
+  if (cap > kBnOnepassBlocks) cap = kBnOnepassBlocks;
+  if (!(counter && bn_onepass() && rows > 0 && cap > 0 && ngran <= (long long)cap * kThreads * kBnHold &&
+        ngran <= bn_onepass_max_granules())) {
+    rc = kd6d_bn_train_bwd_reduce(dtype, x_f32, x, dz, rows, C, mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat,
+                                  replicas, stream);
+    if (rc) return rc;
+    return kd6d_bn_train_bwd_apply(dtype, x_f32, x, dz, dx, rows, C, mean, invstd, gamma, beta, act, sum_dy,
+                                   sum_dy_xhat, dgamma, dbeta, replicas, stream);
+  }
+  KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_train_bwd: replicas=%d outside [1,64]", replicas);
+  KD6D_CHECK_ARG(x && dz && dx && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat,
+                 "kd6d_bn_train_bwd: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long long nb = (ngran + 2 * kThreads - 1) / (2 * kThreads);       // two granules per thread while the device has room
+  if (nb > cap) nb = cap;
+  const int per = (int)((ngran + nb * kThreads - 1) / (nb * kThreads));
+  const float inv_rows = 1.f / (float)rows;
+  DISPATCH_TTX(dtype, x_f32,
+               hipLaunchKernelGGL((bn_bwd_onepass_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads),
+                                  (size_t)2 * C * sizeof(float), st, (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, per,
+                                  C, inv_rows, mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma,
+                                  dbeta, replicas));
+  KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd");
+  return KD6D_OK;
+}
+
 extern "C" int kd6d_barrier_timeouts(void) {
   unsigned int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_barrier_timeouts), sizeof(v)) != hipSuccess) return -1;
@@ -1285,7 +1595,8 @@ extern "C" int kd6d_bn_pool_train_fwd(int dtype, int x_f32, const void* x, void*
 extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, void* dx, int B, int H,
                                       int W, int C, const float* mean, const float* invstd, const float* gamma,
                                       const float* beta, int act, float* sum_dy, float* sum_dy_xhat,
-                                      float* dgamma, float* dbeta, int replicas, void* stream) {
+                                      unsigned int* counter, float* dgamma, float* dbeta, int replicas,
+                                      void* stream) {
   long long items = 0;
   int rc = check_pool(dtype, B, H, W, C, "kd6d_bn_pool_train_bwd", &items);
   if (rc) return rc;
@@ -1299,6 +1610,22 @@ extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const
   if (nbr < 1) nbr = 1;
   const int nba = grid_for(items);
   const size_t lds = (size_t)2 * C * sizeof(float);
+  int cap = 0;
+  DISPATCH_TTX(dtype, x_f32, cap = (bn_onepass_capacity<T_, TX_>(true)));
+  cap = cap * 3 / 4;                                      // the whole grid must be resident for the barrier
+  if (cap > kBnOnepassBlocks) cap = kBnOnepassBlocks;
+  if (counter && bn_onepass() && cap > 0 && items <= (long long)cap * kThreads * kPoolHold &&
+      items * 4 <= bn_onepass_max_granules()) {
+    long long nb1 = (items + kThreads - 1) / kThreads;
+    if (nb1 > cap) nb1 = cap;
+    const int per = (int)((items + nb1 * kThreads - 1) / (nb1 * kThreads));
+    DISPATCH_TTX(dtype, x_f32,
+                 hipLaunchKernelGGL((bn_pool_bwd_onepass_kernel<T_, TX_>), dim3((int)nb1), dim3(kThreads), lds, st,
+                                    (const TX_*)x, (const T_*)dy, (T_*)dx, (int)items, per, H, W, C, inv_rows, mean,
+                                    invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma, dbeta, replicas));
+    KD6D_CHECK_LAUNCH("kd6d_bn_pool_train_bwd");
+    return KD6D_OK;
+  }
   DISPATCH_TTX(dtype, x_f32, {
     hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T_, TX_>), dim3((int)nbr), dim3(kThreads), lds, st,
                        (const TX_*)x, (const T_*)dy, (int)items, H, W, C, mean, invstd, gamma, beta, act, sum_dy,
@@ -1369,6 +1696,11 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
     if (chunk * cgs > kGnHold * kThreads) chunk = kGnHold * kThreads / cgs;
     GnGeom g1;
     KD6D_CHECK_ARG(chunk >= 1 && fill_gn(level_hw_host, nseg, batch, C, groups, &g1, chunk), "kd6d_gn_relu_bwd: geometry");
+    int gcap = 0, gmax = 1;
+    DISPATCH_TTX(dtype, x_f32, gcap = (gn_onepass_capacity<T_, TX_>()));
+    for (int s = 0; s < nseg; ++s) gmax = g1.cps[s] > gmax ? g1.cps[s] : gmax;
+    KD6D_CHECK_ARG(gcap >= 2 * gmax, "kd6d_gn_relu_bwd: a level of %d row chunks does not fit the %d resident workgroups "
+                   "(set KD6D_GN_ONEPASS=0)", gmax, gcap);
     unsigned int* counters = reinterpret_cast<unsigned int*>(gsum_ws + 2 * (size_t)nseg * batch * groups);
     if (!(flags & KD6D_GN_WS_ZEROED) &&
         hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)nseg * batch, st) != hipSuccess) {

@@ -63,7 +63,8 @@ SIGNATURES = {
     "kd6d_bn_train_bwd_apply": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "kd6d_barrier_timeouts": [],
     "kd6d_bn_pool_train_fwd": [_I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
-    "kd6d_bn_pool_train_bwd": [_I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "kd6d_bn_pool_train_bwd": [_I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
+    "kd6d_bn_train_bwd": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P,
                          _P, _P, _P, _I, _P],

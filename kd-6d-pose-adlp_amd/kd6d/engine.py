@@ -250,7 +250,7 @@ class ConvBlock:
         # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
         c = self.conv.cout_p
         geom = self.conv.geom(batch, levels)
-        s = net.scratch(self.name, (4 + 2 * self.bwd_replicas(geom.rows_out)) * c)
+        s = net.scratch(self.name, (4 + 2 * self.bwd_replicas(geom.rows_out)) * c + ops.BARRIER_WORDS)   # + the backward's barrier words
         ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
         # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
         # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
@@ -278,18 +278,19 @@ class ConvBlock:
         net, st = self.net, self.net.store
         c = self.conv.cout_p
         R = self.bwd_replicas(raw.shape[0])
-        s = net.scratch(self.name, (4 + 2 * R) * c)
+        s = net.scratch(self.name, (4 + 2 * R) * c + ops.BARRIER_WORDS)
         mean, invstd = s[2 * c:3 * c], s[3 * c:4 * c]
         w1, w2 = s[4 * c:(4 + R) * c], s[(4 + R) * c:(4 + 2 * R) * c]
+        counter = s[(4 + 2 * R) * c:(4 + 2 * R) * c + ops.BARRIER_WORDS]      # zeroed with the arena at the start of the step
         draw = net.buf(self.name + ".draw", raw.shape, net.dtype)
         if pooled is not None:                  # dz is the gradient of the pooled output
             ops.bn_pool_train_bwd(raw, dz, draw, batch, pooled[0], pooled[1], mean, invstd, st.storage(self.bn.gamma),
                                   st.storage(self.bn.beta), ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"),
-                                  st.storage(self.bn.beta, "grads"), replicas=R)
+                                  st.storage(self.bn.beta, "grads"), replicas=R, counter=counter)
         else:
             ops.bn_train_bwd(raw, dz, draw, mean, invstd, st.storage(self.bn.gamma), st.storage(self.bn.beta),
                              ACT_LEAKY, w1, w2, st.storage(self.bn.gamma, "grads"), st.storage(self.bn.beta, "grads"),
-                             replicas=R)
+                             replicas=R, counter=counter)
         return self.conv.bwd(x, draw, batch, levels, need_dx=need_dx, dx=dx, accumulate=accumulate)
 
 

@@ -200,19 +200,19 @@ def bn_train_fwd(x, y, sum_, sumsq, gamma, beta, eps, momentum, running_mean, ru
     return y
 
 
-def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta, replicas=1):
-    """ws_sum_dy / ws_sum_dy_xhat: `replicas` rows of C floats each, pre-zeroed (kd6d.h)."""
+BARRIER_WORDS = 32          # KD6D_BARRIER_WORDS: pre-zeroed 32-bit words of an in-kernel barrier (kd6d.h)
+
+
+def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta, replicas=1,
+                 counter=None):
+    """ws_sum_dy / ws_sum_dy_xhat: `replicas` rows of C floats each, pre-zeroed (kd6d.h).  counter: BARRIER_WORDS
+    pre-zeroed 32-bit words -> the one-launch backward (in-kernel barrier) when the tensor fits; None -> reduce + apply."""
     rows, c = x.shape
     assert ws_sum_dy.numel() >= replicas * c and ws_sum_dy_xhat.numel() >= replicas * c
-    code = dt_code(dz.dtype)
-    xf = _xf32(x, dz.dtype)
-    check(lib.kd6d_bn_train_bwd_reduce(code, xf, _ptr(x), _ptr(dz), rows, c, _ptr(mean), _ptr(invstd),
-                                       _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
-                                       _ptr(ws_sum_dy_xhat), replicas, _stream()), "kd6d_bn_train_bwd_reduce")
-    check(lib.kd6d_bn_train_bwd_apply(code, xf, _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
-                                      _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
-                                      _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), replicas, _stream()),
-          "kd6d_bn_train_bwd_apply")
+    assert counter is None or counter.numel() >= BARRIER_WORDS
+    check(lib.kd6d_bn_train_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
+                                _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy), _ptr(ws_sum_dy_xhat),
+                                _ptr(counter), _ptr(dgamma), _ptr(dbeta), replicas, _stream()), "kd6d_bn_train_bwd")
     return dx
 
 
@@ -229,15 +229,17 @@ def bn_pool_train_fwd(x, y, batch, h, w, sum_, sumsq, gamma, beta, eps, momentum
 
 
 def bn_pool_train_bwd(x, dy, dx, batch, h, w, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma,
-                      dbeta, replicas=1):
-    """dy: gradient of the POOLED output; dx: gradient of the conv output x (same rows as x, dtype of dy)."""
+                      dbeta, replicas=1, counter=None):
+    """dy: gradient of the POOLED output; dx: gradient of the conv output x (same rows as x, dtype of dy);
+    counter as in bn_train_bwd."""
     rows, c = x.shape
     assert rows == batch * h * w and tuple(dy.shape) == (batch * (h // 2) * (w // 2), c) and dx.shape == x.shape
     assert ws_sum_dy.numel() >= replicas * c and ws_sum_dy_xhat.numel() >= replicas * c
+    assert counter is None or counter.numel() >= BARRIER_WORDS
     check(lib.kd6d_bn_pool_train_bwd(dt_code(dy.dtype), _xf32(x, dy.dtype), _ptr(x), _ptr(dy), _ptr(dx), batch, h, w,
                                      c, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
-                                     _ptr(ws_sum_dy_xhat), _ptr(dgamma), _ptr(dbeta), replicas, _stream()),
-          "kd6d_bn_pool_train_bwd")
+                                     _ptr(ws_sum_dy_xhat), _ptr(counter), _ptr(dgamma), _ptr(dbeta), replicas,
+                                     _stream()), "kd6d_bn_pool_train_bwd")
     return dx
 
 

@@ -6,6 +6,8 @@ bf16 kernels are checked on bf16-representable inputs against an fp32 CPU result
 only differences are fp32 accumulation order (tolerance 2e-5 * sum|a*b| bound, stated per
 test) and, where the output is stored in bf16, one bf16 rounding (2^-8 relative).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -327,9 +329,14 @@ MIXED = [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, False)
 
 
 @pytest.mark.parametrize("dtype,xf32", MIXED)
-@pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64)])
-def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows):
+@pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64), (8, 300000), (16, 70001)])
+@pytest.mark.parametrize("onepass", [False, True])
+def test_batchnorm_train_fwd_bwd(gpu_device, monkeypatch, dtype, xf32, C, rows, onepass):
+    """onepass: the backward as one launch whose workgroups meet at an in-kernel barrier (kd6d_bn_train_bwd with a
+    counter; the size limit is lifted so that the long tensors run 512-workgroup grids) against the reduce + apply
+    pair."""
     ops = _ops()
+    monkeypatch.setenv("KD6D_BN_ONEPASS_MAX", str(1 << 40))
     dev = gpu_device
     g = torch.Generator().manual_seed(C + rows)
     x = round_to(torch.randn(rows, C, generator=g) * 2 + 0.5, torch.float32 if xf32 else dtype)
@@ -355,8 +362,15 @@ def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows):
     R = 1 if rows < 1000 else 8            # replica rows of the backward accumulators (kd6d.h)
     w1 = torch.zeros(R * C, device=dev); w2 = torch.zeros(R * C, device=dev)
     dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
-    ops.bn_train_bwd(xd, dzd, dx, mean, invstd, gamma.to(dev), beta.to(dev), 1, w1, w2, dgam, dbet, replicas=R)
+    counter = torch.zeros(32, dtype=torch.int32, device=dev) if onepass else None
+    ops.bn_train_bwd(xd, dzd, dx, mean, invstd, gamma.to(dev), beta.to(dev), 1, w1, w2, dgam, dbet, replicas=R,
+                     counter=counter)
     torch.cuda.synchronize()
+    assert ops.lib.kd6d_barrier_timeouts() == 0
+    if onepass:
+        eg = 4 if dtype == torch.float32 else 8
+        fits = rows * (C // eg) <= 512 * 256 * 4        # 512 resident workgroups x 4 granules per thread (kd6d.h)
+        assert (int(counter[0].item()) > 0) == fits, "one-launch path taken / not taken against the documented rule"
     tol = _tol(dtype, stored=True)
     torch.testing.assert_close(y.cpu().double(), yr.detach(), **tol)
     torch.testing.assert_close(rm_d.cpu().double(), rmr, rtol=1e-4, atol=1e-5)
@@ -370,13 +384,14 @@ def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,xf32", [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 16, 16, 64), (2, 64, 64, 16), (16, 64, 64, 8), (1, 2, 2, 256)])
-def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H, W, C):
+def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, monkeypatch, dtype, xf32, B, H, W, C):
     """BN(train)+LeakyReLU+MaxPool2d(2,2) as one kernel (darknet.py:94-97 behind a ConvBlock): the pooled output is
     bit-identical to bn_train_fwd -> maxpool2_fwd, the backward matches bn_train_bwd(maxpool2_bwd(.)) up to the
     order of the fp32 reductions, and both agree with torch autograd in float64.  Ties inside a window (common in
     bf16) exercise the first-maximum rule."""
     ops = _ops()
     dev = gpu_device
+    monkeypatch.setenv("KD6D_BN_ONEPASS_MAX", str(1 << 40))      # the one-launch backward at every size
     if dtype == torch.float32 and C % 4:
         pytest.skip("granule")
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + C)
@@ -394,7 +409,8 @@ def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H
     ops.colstats(xd, s1, s2)
     R = 1 if rows < 1000 else 8
 
-    def run(fused):
+    def run(fused, onepass=False):
+        counter = torch.zeros(32, dtype=torch.int32, device=dev) if onepass else None
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
         w1 = torch.zeros(R * C, device=dev); w2 = torch.zeros(R * C, device=dev)
@@ -403,7 +419,8 @@ def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H
         dx = torch.empty(rows, C, dtype=dtype, device=dev)
         if fused:
             ops.bn_pool_train_fwd(xd, yp, B, H, W, s1, s2, gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
-            ops.bn_pool_train_bwd(xd, dyd, dx, B, H, W, mean, invstd, gamma, beta, 1, w1, w2, dgam, dbet, replicas=R)
+            ops.bn_pool_train_bwd(xd, dyd, dx, B, H, W, mean, invstd, gamma, beta, 1, w1, w2, dgam, dbet, replicas=R,
+                                  counter=counter)
         else:
             z = torch.empty(rows, C, dtype=dtype, device=dev)
             ops.bn_train_fwd(xd, z, s1, s2, gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
@@ -416,6 +433,11 @@ def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H
 
     fy, fdx, fdg, fdb, frm, frv = run(True)
     uy, udx, udg, udb, urm, urv = run(False)
+    oy, odx, odg, odb, _, _ = run(True, onepass=True)       # backward as one launch (in-kernel barrier)
+    assert ops.lib.kd6d_barrier_timeouts() == 0
+    torch.testing.assert_close(odx.double(), fdx.double(), **_tol(dtype, stored=True))
+    torch.testing.assert_close(odg, fdg, rtol=1e-4, atol=1e-4 * max(1.0, float(fdg.abs().max())))
+    torch.testing.assert_close(odb, fdb, rtol=1e-4, atol=1e-4 * max(1.0, float(fdg.abs().max())))
     assert torch.equal(fy, uy)
     assert torch.equal(frm, urm) and torch.equal(frv, urv)
     tol = _tol(dtype, stored=True)
@@ -432,6 +454,70 @@ def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H
         torch.testing.assert_close(fy.double(), p.detach(), rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(fdx.double(), xr.grad, rtol=2e-3, atol=2e-3)
         torch.testing.assert_close(fdg.double(), gr.grad, rtol=1e-3, atol=1e-3 * gs)
+
+
+def test_in_kernel_barriers_under_repetition(gpu_device, monkeypatch):
+    """The one-launch BN / GN backward kernels exchange partial sums across workgroups inside the launch.  300
+    back-to-back launches each (512- and 274-workgroup BN grids, 8-workgroup GN sibling groups) must all reproduce
+    the two-launch result: a workgroup that left the barrier before a sibling's partial sum was visible would miss
+    ~1/274 of a total, far outside the tolerance.  No barrier may time out."""
+    ops = _ops()
+    dev = gpu_device
+    monkeypatch.setenv("KD6D_BN_ONEPASS_MAX", str(1 << 40))
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(99)
+    for C, rows in [(16, 70001), (64, 65536)]:
+        x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dev)
+        dz = (torch.rand(rows, C, generator=g) + 0.5).to(bf).to(dev)         # positive: large, stable sums
+        gamma = (torch.rand(C, generator=g) + 0.5).to(dev); beta = torch.zeros(C, device=dev)
+        s1 = torch.zeros(C, device=dev); s2 = torch.zeros(C, device=dev)
+        ops.colstats(x, s1, s2)
+        mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
+        y = torch.empty(rows, C, dtype=bf, device=dev)
+        ops.bn_train_fwd(x, y, s1, s2, gamma, beta, 1e-5, 0.1, torch.zeros(C, device=dev), torch.ones(C, device=dev),
+                         mean, invstd, 1)
+
+        def bwd(counter):
+            w1 = torch.zeros(8 * C, device=dev); w2 = torch.zeros(8 * C, device=dev)
+            dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+            dx = torch.empty(rows, C, dtype=bf, device=dev)
+            ops.bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, 1, w1, w2, dg, db, replicas=8, counter=counter)
+            return dx, dg, db
+
+        rdx, rdg, rdb = bwd(None)
+        for it in range(300):
+            counter = torch.zeros(32, dtype=torch.int32, device=dev)
+            dx, dg, db = bwd(counter)
+            assert float((dg - rdg).abs().max()) <= 2e-5 * float(rdg.abs().max()) + 1e-3, (C, rows, it)
+            assert float((db - rdb).abs().max()) <= 2e-5 * float(rdb.abs().max()) + 1e-3, (C, rows, it)
+            assert float((dx.float() - rdx.float()).abs().max()) <= 2e-2, (C, rows, it)
+    # GroupNorm: 32x32 level -> 8 sibling workgroups per image
+    C, G, B, levels = 128, 32, 4, [(32, 32), (16, 16)]
+    hw = [h * w for h, w in levels]
+    rows = B * sum(hw)
+    x = torch.randn(rows, C, generator=g).to(dev)
+    dz = (torch.rand(rows, C, generator=g) + 0.5).to(bf).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev); beta = (torch.rand(C, generator=g)).to(dev)
+    stats = torch.empty(len(levels) * B * G * 2, device=dev)
+    y = torch.empty(rows, C, dtype=bf, device=dev)
+    ops.gn_relu_fwd(x, y, hw, B, G, gamma, beta, 1e-5, stats)
+    ref = None
+    for it in range(301):
+        os.environ["KD6D_GN_ONEPASS"] = "0" if it == 0 else "1"
+        try:
+            gsum = torch.empty(ops.gn_bwd_workspace_floats(len(levels), B, G), device=dev)
+            dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+            dx = torch.empty(rows, C, dtype=bf, device=dev)
+            ops.gn_relu_bwd(x, dz, dx, hw, B, G, gamma, beta, stats, gsum, dg, db)
+        finally:
+            os.environ.pop("KD6D_GN_ONEPASS", None)
+        if it == 0:
+            ref = (dx.float(), dg.clone())
+        else:
+            assert float((dx.float() - ref[0]).abs().max()) <= 2e-2, it
+            assert float((dg - ref[1]).abs().max()) <= 2e-5 * float(ref[1].abs().max()) + 1e-3, it
+    torch.cuda.synchronize()
+    assert ops.lib.kd6d_barrier_timeouts() == 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -73,6 +73,20 @@ def main():
 
         row(name, "bn_bwd_reduce", rows, c, mb_x + mb_a, timeit_graph(reduce_only, a.iters))
         row(name, "bn_bwd_apply", rows, c, mb_x + 2 * mb_a, timeit_graph(apply_only, a.iters))
+        ctr = torch.zeros(32, dtype=torch.int32, device=dev)
+
+        def onepass():      # the counter (and the sums) are NOT re-zeroed between the timed launches: the barrier is
+            ctr.zero_()     # passed at once after the first -- so zero it inside the timed region (one small memset)
+            ops.bn_train_bwd(x, dz, dx, s[2 * c:3 * c], s[3 * c:4 * c], gamma, beta, 1, s[4 * c:(4 + R) * c],
+                             s[(4 + R) * c:], dg, db, replicas=R, counter=ctr)
+
+        def pair():
+            ctr.zero_()
+            ops.bn_train_bwd(x, dz, dx, s[2 * c:3 * c], s[3 * c:4 * c], gamma, beta, 1, s[4 * c:(4 + R) * c],
+                             s[(4 + R) * c:], dg, db, replicas=R, counter=None)
+
+        row(name, "bn_bwd pair + memset", rows, c, 2 * mb_x + 3 * mb_a, timeit_graph(pair, a.iters))
+        row(name, "bn_bwd one launch + memset", rows, c, mb_x + 2 * mb_a, timeit_graph(onepass, a.iters))
 
     # the four ConvBlocks that sit in front of a MaxPool2d(2,2): fused BN + act + pool against the separate launches
     for name, side, c in [("u1", 256, 8), ("u2", 128, 16), ("s3.last", 64, 64), ("s4.last", 32, 128)]:
