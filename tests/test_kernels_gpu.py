@@ -490,7 +490,7 @@ def test_in_kernel_barriers_under_repetition(gpu_device, monkeypatch):
             dx, dg, db = bwd(counter)
             assert float((dg - rdg).abs().max()) <= 2e-5 * float(rdg.abs().max()) + 1e-3, (C, rows, it)
             assert float((db - rdb).abs().max()) <= 2e-5 * float(rdb.abs().max()) + 1e-3, (C, rows, it)
-            assert float((dx.float() - rdx.float()).abs().max()) <= 2e-2, (C, rows, it)
+            assert bool(((dx.float() - rdx.float()).abs() <= 2e-2 * rdx.float().abs().clamp(min=1.0)).all()), (C, rows, it)
     # GroupNorm: 32x32 level -> 8 sibling workgroups per image
     C, G, B, levels = 128, 32, 4, [(32, 32), (16, 16)]
     hw = [h * w for h, w in levels]
@@ -514,7 +514,7 @@ def test_in_kernel_barriers_under_repetition(gpu_device, monkeypatch):
         if it == 0:
             ref = (dx.float(), dg.clone())
         else:
-            assert float((dx.float() - ref[0]).abs().max()) <= 2e-2, it
+            assert bool(((dx.float() - ref[0]).abs() <= 2e-2 * ref[0].abs().clamp(min=1.0)).all()), it
             assert float((dg - ref[1]).abs().max()) <= 2e-5 * float(ref[1].abs().max()) + 1e-3, it
     torch.cuda.synchronize()
     assert ops.lib.kd6d_barrier_timeouts() == 0
