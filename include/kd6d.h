@@ -66,6 +66,17 @@ typedef struct kd6d_conv_geom {
 const char* kd6d_last_error(void);
 int kd6d_abi_version(void);
 
+/* Pair bracket: between _begin and _end, convolutions that resolve to the 3x3 "halo patch" kernel (forward or
+ * data gradient) are recorded instead of launched; _end issues two recorded launches of the same kernel variant,
+ * geometry and stream as ONE launch (workgroups of both convolutions in one grid), anything else one by one, in
+ * call order.  For two independent convolutions of identical shape that each fill only part of the device -- the
+ * cls and the pose tower layer of the head (models/model.py:438-451).  Everything else called inside the bracket
+ * launches immediately; the recorded convolutions run at _end, so nothing inside the bracket may depend on them.
+ * Thread-local; not nestable. */
+int kd6d_conv2d_pair_begin(void);
+int kd6d_conv2d_pair_end(void);
+int kd6d_conv2d_pair_pending(void);   /* launches recorded so far in the open bracket (0 outside one) */
+
 /* ---- convolution: replaces torch conv2d inside backbone/common.py:316-324
  * (ConvBlock), models/model.py:64-83,97-103 (FPN) and :438-451 (PoseHead).
  * Implicit GEMM on MFMA, weights KRSC: w[cout][ky][kx][cin].

@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvParams p
 // one raw s_barrier per k-step.  Levels of a multi-level (head) launch may share a tile.
 // ---------------------------------------------------------------------------
 template <int BP, int BC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
+__device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int total_rows, int bid, int nwg) {
   using T = bf16_t;
   constexpr int NW = WP * WC;
   constexpr int PI = BP / WP / 16;
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvPar
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wg = xcd_remap(bid, nwg);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -984,6 +984,22 @@ __global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvPar
     }
   }
   conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+}
+
+template <int BP, int BC, int WP, int WC, int MODE>
+__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
+  halo_tile<BP, BC, WP, WC, MODE>(p, halo, total_rows, blockIdx.x, gridDim.x);
+}
+
+// Two convolutions of identical geometry (the cls and the pose tower layer of the head: different tensors and
+// weights, same shapes) as ONE launch: workgroups [0, tiles_a) run `pa`, the rest `pb`.  A student tower layer
+// alone is 170 tiles of 128x128 on 256 CUs, one 128-KB workgroup per CU -- a second stream cannot use the idle
+// third; as a pair the two layers are 228 tiles of 192x128, one full round for both.
+template <int BP, int BC, int WP, int WC, int MODE>
+__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_pair_kernel(const ConvParams pa, const ConvParams pb,
+                                                                        int halo, int total_rows, int tiles_a) {
+  if ((int)blockIdx.x < tiles_a) halo_tile<BP, BC, WP, WC, MODE>(pa, halo, total_rows, blockIdx.x, tiles_a);
+  else halo_tile<BP, BC, WP, WC, MODE>(pb, halo, total_rows, blockIdx.x - tiles_a, gridDim.x - tiles_a);
 }
 
 // ---------------------------------------------------------------------------
@@ -1827,16 +1843,33 @@ int cached_cu_count() {       // one device per process
   return n;
 }
 
+// kd6d_conv2d_pair_begin / _end: between the two calls, halo-kernel launches are recorded instead of issued; two
+// recorded launches of the same kernel variant and geometry go out as one conv3x3_halo_pair_kernel launch.
+struct HaloRecord {
+  ConvParams q;
+  int halo, total_rows, tiles;
+  hipStream_t st;
+  void (*single)(const HaloRecord&);
+  void (*pair)(const HaloRecord&, const HaloRecord&);
+};
+struct PairState {
+  bool active = false;
+  int count = 0;
+  HaloRecord rec[2];
+};
+thread_local PairState g_pair;
+
 template <int BP, int BC, int WP, int WC, int MODE>
-void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
+size_t halo_lds() {
   constexpr int NW = WP * WC;
   constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;
   constexpr int PL = (PSLOT + NW - 1) / NW;
-  ConvParams q = p;
-  q.n_ctiles = (p.N + BC - 1) / BC;
-  const int ptiles = (p.M + BP - 1) / BP;
-  set_tile_order(q, ptiles, BP, BC);
-  const size_t lds = (size_t)2 * PL * NW * 1024 + (size_t)3 * BC * 128;
+  return (size_t)2 * PL * NW * 1024 + (size_t)3 * BC * 128;
+}
+
+template <int BP, int BC, int WP, int WC, int MODE>
+void halo_issue_single(const HaloRecord& r) {
+  const size_t lds = halo_lds<BP, BC, WP, WC, MODE>();
   auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1844,7 +1877,35 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(NW * 64), lds, st, q, halo, total_rows);
+  hipLaunchKernelGGL(kern, dim3(r.tiles), dim3(WP * WC * 64), lds, r.st, r.q, r.halo, r.total_rows);
+}
+
+template <int BP, int BC, int WP, int WC, int MODE>
+void halo_issue_pair(const HaloRecord& a, const HaloRecord& b) {
+  const size_t lds = halo_lds<BP, BC, WP, WC, MODE>();
+  auto kern = conv3x3_halo_pair_kernel<BP, BC, WP, WC, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles + b.tiles), dim3(WP * WC * 64), lds, a.st, a.q, b.q, a.halo, a.total_rows,
+                     a.tiles);
+}
+
+template <int BP, int BC, int WP, int WC, int MODE>
+void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
+  HaloRecord r;
+  r.q = p;
+  r.q.n_ctiles = (p.N + BC - 1) / BC;
+  const int ptiles = (p.M + BP - 1) / BP;
+  set_tile_order(r.q, ptiles, BP, BC);
+  r.halo = halo; r.total_rows = total_rows; r.tiles = ptiles * r.q.n_ctiles; r.st = st;
+  r.single = &halo_issue_single<BP, BC, WP, WC, MODE>;
+  r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE>;
+  if (g_pair.active && g_pair.count < 2) { g_pair.rec[g_pair.count++] = r; return; }
+  r.single(r);
 }
 
 // 3x3/s1/p1 layers with C % 64 == 0 on maps at most 64 wide, both sides packed identically.
@@ -1875,7 +1936,9 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   //   128x64  from >= 64 workgroups (teacher stage 4, student FPN 32x32 level) -- ahead of split-K;
   //   192x128 / 64x64 / 128x32: the tile-count corner cases below;
   // below that the layer goes to split-K / the generic kernels.
-  const int pt128 = (p.M + 127) / 128;
+  // inside a kd6d_conv2d_pair_begin/_end bracket the launch shares the device with its twin: count tiles twice
+  const int pf = g_pair.active ? 2 : 1;
+  const int pt128 = pf * ((p.M + 127) / 128);
   int pick = 0;
   const int ct128 = (p.N + 127) / 128;
   const int ncu = cached_cu_count();
@@ -1883,12 +1946,12 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   // few result channels (cls logits, dgrad into the narrow student stages): 128 x 32, or 64 x 64 on small maps
   if (p.N <= 32) pick = pt128 <= ncu / 2 ? 9 : 5;
   // 128 x 64 tiles would occupy at most half of the CUs: 64 x 64 (FPN 16x16 level, stage 5, student FPN)
-  else if (pt128 * ct64 <= ncu / 2 && ((p.M + 63) / 64) * ct64 >= 64) pick = 9;
+  else if (pt128 * ct64 <= ncu / 2 && pf * ((p.M + 63) / 64) * ct64 >= 64) pick = 9;
   // 192 x 128 where it turns 256-pixel tiles that leave a third of the CUs idle into one full round (teacher head
   // towers: 172 tiles of 256 pixels on 256 CUs -> 228 tiles of 192)
-  else if (((p.M + 255) / 256) * ct128 >= 150 && ((p.M + 255) / 256) * ct128 <= (3 * ncu) / 4 &&
-           ((p.M + 191) / 192) * ct128 <= ncu) pick = 6;
-  else if (((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
+  else if (pf * ((p.M + 255) / 256) * ct128 >= 150 && pf * ((p.M + 255) / 256) * ct128 <= (3 * ncu) / 4 &&
+           pf * ((p.M + 191) / 192) * ct128 <= ncu) pick = 6;
+  else if (pf * ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
   else if (pt128 * ((p.N + 127) / 128) >= 160) pick = 3;
   else if (pt128 * ((p.N + 63) / 64) >= 64) pick = 4;
   if (force > 0) pick = force;
@@ -2207,6 +2270,31 @@ void dispatch_wgrad(const WgradParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int kd6d_conv2d_pair_begin(void) {
+  KD6D_CHECK_ARG(!g_pair.active, "kd6d_conv2d_pair_begin: already inside a pair bracket");
+  g_pair.active = true;
+  g_pair.count = 0;
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_conv2d_pair_pending(void) { return g_pair.active ? g_pair.count : 0; }
+
+extern "C" int kd6d_conv2d_pair_end(void) {
+  KD6D_CHECK_ARG(g_pair.active, "kd6d_conv2d_pair_end: no pair bracket open");
+  g_pair.active = false;
+  const int n = g_pair.count;
+  g_pair.count = 0;
+  const HaloRecord& a = g_pair.rec[0];
+  const HaloRecord& b = g_pair.rec[1];
+  if (n == 2 && a.pair == b.pair && a.halo == b.halo && a.total_rows == b.total_rows && a.st == b.st) {
+    a.pair(a, b);
+  } else {
+    for (int i = 0; i < n; ++i) g_pair.rec[i].single(g_pair.rec[i]);
+  }
+  KD6D_CHECK_LAUNCH("kd6d_conv2d_pair_end");
+  return KD6D_OK;
+}
 
 extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
                                void* y, const float* ch_scale, const float* ch_shift, int act,

@@ -62,6 +62,9 @@ SIGNATURES = {
     "kd6d_bn_train_bwd_reduce": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "kd6d_bn_train_bwd_apply": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "kd6d_barrier_timeouts": [],
+    "kd6d_conv2d_pair_begin": [],
+    "kd6d_conv2d_pair_end": [],
+    "kd6d_conv2d_pair_pending": [],
     "kd6d_bn_pool_train_fwd": [_I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     "kd6d_bn_pool_train_bwd": [_I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "kd6d_bn_train_bwd": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],

@@ -344,6 +344,8 @@ class PoseNet:
         self.side_streams = None       # optional list: consecutive weight gradients rotate over these streams
         self.wgrad_cu_budget = 0       # CUs each forked weight gradient aims to fill (0 = the device)
         self.fuse_pool = os.environ.get("KD6D_FUSE_POOL", "1") != "0"   # BN + act + maxpool as one kernel (training)
+        # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
+        self.pair_towers = int(os.environ.get("KD6D_PAIR_TOWERS", "1"))
         self._side_rr = 0
         feat, oc = BACKBONE_CFG[arch]
         self.out_channel = oc
@@ -620,7 +622,33 @@ class PoseNet:
         # ---- head over all levels at once ----
         self.head_ctx = {}
         outs = {}
-        for tname, tower, final in (("cls", self.cls_tower, self.cls_logits), ("pose", self.pose_tower, self.pose_pred)):
+        towers = (("cls", self.cls_tower, self.cls_logits), ("pose", self.pose_tower, self.pose_pred))
+        if self.training and self.pair_towers:
+            # layer by layer through BOTH towers: the two convolutions of a layer have identical geometry and go
+            # out as one launch (ops.conv_pair: 228 tiles of 192x128 instead of 2 x 170 tiles of 128x128)
+            xs = {t: head_in for t, _, _ in towers}
+            saved = {t: [] for t, _, _ in towers}
+            for li in range(len(self.cls_tower)):
+                raws = {}
+                with ops.conv_pair():
+                    for tname, tower, _ in towers:
+                        conv, gn = tower[li]
+                        raws[tname], _ = conv.fwd(xs[tname], B, levels_all, out_f32=True,
+                                                  out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32),
+                                                  stats=gn.stats(B, levels_all), stats_groups=gn.groups)
+                for tname, tower, _ in towers:
+                    gn = tower[li][1]
+                    y = gn.fwd(raws[tname], B, levels_all, out=self.buf("%s.act%d" % (tname, li), (r, oc)))
+                    saved[tname].append((xs[tname], raws[tname]))
+                    xs[tname] = y
+            for tname, tower, final in towers:
+                seg = self.store.storage(self.scales) if tname == "pose" else None
+                out, _ = final.fwd(xs[tname], B, levels_all, seg_scale=seg, out_f32=True,
+                                   out=self.buf("%s.logits" % tname, (r, final.cout_p), torch.float32))
+                self.head_ctx[tname] = (saved[tname], xs[tname])
+                outs[tname] = out
+            return outs["cls"], outs["pose"]
+        for tname, tower, final in towers:
             x = head_in
             saved = []
             for li, (conv, gn) in enumerate(tower):
@@ -645,8 +673,31 @@ class PoseNet:
         B, lv_all, r, oc = self.batch, self.levels, self.rows, self.out_channel
         d_head_in = self.buf("d_head_in", (r, oc))
         first = True
-        for tname, tower, final, dlog in (("cls", self.cls_tower, self.cls_logits, dcls),
-                                          ("pose", self.pose_tower, self.pose_pred, dreg)):
+        towers = (("cls", self.cls_tower, self.cls_logits, dcls), ("pose", self.pose_tower, self.pose_pred, dreg))
+        if self.pair_towers:
+            dxs = {}
+            for tname, tower, final, dlog in towers:
+                saved, last = self.head_ctx[tname]
+                dxs[tname] = final.bwd(last, dlog, B, lv_all, dx=self.buf("%s.dact" % tname, (r, oc)))
+            for li in range(len(self.cls_tower) - 1, -1, -1):
+                draws = {}
+                for tname, tower, _, _ in towers:
+                    gn = tower[li][1]
+                    draws[tname] = gn.bwd(self.head_ctx[tname][0][li][1], dxs[tname], B, lv_all,
+                                          self.buf("%s.draw%d" % (tname, li), (r, oc)))
+                if li > 0:
+                    # the two data gradients as one launch; the weight gradients fork onto the side streams as usual
+                    with ops.conv_pair(enabled=self.pair_towers == 1):
+                        for tname, tower, _, _ in towers:
+                            conv = tower[li][0]
+                            dxs[tname] = conv.bwd(self.head_ctx[tname][0][li][0], draws[tname], B, lv_all,
+                                                  dx=self.buf("%s.dact" % tname, (r, oc)))
+                else:   # both towers add into d_head_in: one after the other
+                    for k, (tname, tower, _, _) in enumerate(towers):
+                        tower[0][0].bwd(self.head_ctx[tname][0][0][0], draws[tname], B, lv_all, dx=d_head_in,
+                                        accumulate=k > 0)
+            towers = ()
+        for tname, tower, final, dlog in towers:
             saved, last = self.head_ctx[tname]
             dx = final.bwd(last, dlog, B, lv_all, dx=self.buf("%s.dact" % tname, (r, oc)))
             for li in range(len(tower) - 1, -1, -1):

@@ -51,19 +51,27 @@ def profile_end():
     return [(k, f, e0.elapsed_time(e1), t) for (k, f, e0, e1, t) in rec]
 
 
+_pair_deferred = None      # inside a conv_pair bracket while profiling: (kind, flops, tag) of the recorded launches
+
+
 class _Timed:
-    __slots__ = ("kind", "flops", "e0", "tag")
+    __slots__ = ("kind", "flops", "e0", "tag", "n0")
 
     def __init__(self, kind, flops, tag=None):
-        self.kind, self.flops, self.e0, self.tag = kind, flops, None, tag
+        self.kind, self.flops, self.e0, self.tag, self.n0 = kind, flops, None, tag, 0
 
     def __enter__(self):
         if _prof is not None:
+            if _pair_deferred is not None:
+                self.n0 = lib.kd6d_conv2d_pair_pending()
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *a):
         if self.e0 is not None:
+            if _pair_deferred is not None and lib.kd6d_conv2d_pair_pending() > self.n0:
+                _pair_deferred.append((self.kind, self.flops, self.tag))     # launched (and timed) when the bracket closes
+                return
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             _prof.append((self.kind, self.flops, self.e0, e1, self.tag))
@@ -214,6 +222,37 @@ def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy
                                 _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy), _ptr(ws_sum_dy_xhat),
                                 _ptr(counter), _ptr(dgamma), _ptr(dbeta), replicas, _stream()), "kd6d_bn_train_bwd")
     return dx
+
+
+class conv_pair:
+    """`with ops.conv_pair(): convA(...); convB(...)` -- two independent, identically shaped 3x3 convolutions
+    (forward or data gradient) as one launch (kd6d_conv2d_pair_begin/_end in kd6d.h).  The two convolutions run
+    when the block closes: nothing inside it may consume their results."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _pair_deferred
+        if self.enabled:
+            check(lib.kd6d_conv2d_pair_begin(), "kd6d_conv2d_pair_begin")
+            if _prof is not None:
+                _pair_deferred = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pair_deferred
+        if self.enabled:
+            deferred, _pair_deferred = _pair_deferred, None
+            if deferred:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.kd6d_conv2d_pair_end(), "kd6d_conv2d_pair_end")
+            if deferred:       # one launch: its duration against the work of both convolutions
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                _prof.append((deferred[0][0], sum(d[1] for d in deferred), e0, e1, deferred[0][2]))
+        return False
 
 
 def bn_pool_train_fwd(x, y, batch, h, w, sum_, sumsq, gamma, beta, eps, momentum, running_mean, running_var,

@@ -171,6 +171,56 @@ def test_conv_dgrad(gpu_device, dtype, case):
         torch.testing.assert_close(ga, ref + d0, **_tol(dtype, stored=True))
 
 
+@pytest.mark.parametrize("B,levels", [(16, [(32, 32), (16, 16), (8, 8), (4, 4)]), (2, [(32, 32), (16, 16), (8, 8), (4, 4)]),
+                                      (3, [(20, 12), (7, 5)])])
+def test_conv_pair_bracket_matches_separate_launches(gpu_device, B, levels):
+    """ops.conv_pair: the cls- and pose-tower convolutions of a head layer (same geometry, different tensors,
+    weights, biases and GroupNorm statistics) as ONE launch -- forward with fused bias + statistics, then the two
+    data gradients.  Same values as two separate launches (the per-output summation order does not depend on the
+    tile), and the separate launches are checked against torch elsewhere in this file.  B = 16 is the student
+    head of the benchmark (228 tiles of 192x128 for the pair)."""
+    ops = _ops()
+    dev = gpu_device
+    dtype = torch.bfloat16
+    C, G = 128, 32
+    g = torch.Generator().manual_seed(B)
+    geom = ops.Geom(B, C, C, 3, 1, 1, levels)
+    rows = geom.rows_out
+
+    def mk():
+        x = round_to(torch.randn(rows, C, generator=g), dtype).to(dtype).to(dev)
+        w = round_to(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5, dtype)
+        bias = torch.randn(C, generator=g).to(dev)
+        return x, w_to_krsc(w, dtype).to(dev), w_to_dgrad(w, dtype).to(dev), bias
+
+    A, Bt = mk(), mk()
+    n_stats = len(levels) * B * G * 2
+
+    def run(paired):
+        outs = []
+        with ops.conv_pair(enabled=paired):
+            for x, wk, wt, bias in (A, Bt):
+                stats = torch.zeros(n_stats, device=dev)
+                y = ops.conv2d_fwd(geom, x, wk, ch_shift=bias, out_f32=True, stats=stats, stats_groups=G)
+                outs.append((y, stats))
+        dxs = []
+        with ops.conv_pair(enabled=paired):
+            for (x, wk, wt, bias), (y, _) in zip((A, Bt), outs):
+                dxs.append(ops.conv2d_dgrad(geom, x, wt))          # any (rows, C) tensor serves as dy
+        torch.cuda.synchronize()
+        return [(y.cpu(), st.cpu()) for y, st in outs], [d.cpu() for d in dxs]
+
+    (fa, fb), (da, db) = run(True)
+    (ra, rb), (ea, eb) = run(False)
+    for (y, st), (yr, sr) in ((fa, ra), (fb, rb)):
+        torch.testing.assert_close(y, yr, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(st, sr, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(da.float(), ea.float(), rtol=0, atol=0)
+    torch.testing.assert_close(db.float(), eb.float(), rtol=0, atol=0)
+    assert not torch.equal(fa[0], fb[0])
+    assert ops.lib.kd6d_conv2d_pair_pending() == 0
+
+
 WGRAD_EXTRA = [
     # 128-wide dW tiles (the LDS-DMA ring kernel): several taps per 128-column row, partial j-tile, odd sizes
     (2, 16, 128, 3, 1, [(32, 32)]),
