@@ -21,6 +21,8 @@ still gets exactly one teacher forward and one student step; the losses returned
 to batch k-1 and `flush()` trains on the last pending batch.  The critical path of a call drops from
 teacher + student to max(teacher, student), and the two halves fill each other's idle CUs.
 """
+import os
+
 import torch
 
 from . import ops
@@ -31,6 +33,9 @@ from .libs.poses import ImageList
 
 class GraphedKDStep:
     WGRAD_STREAMS = 4          # weight-gradient launches kept in flight beside the dgrad / normalisation chain
+    # ... each sized (split-K count) for CUs / this many.  Pipelined steps (a teacher forward shares the device for
+    # the first 60 % of the step): CUs / 2; strictly sequential steps: CUs / 4 (4242 against 4168 images/s).
+    WGRAD_BUDGET_DIV = {True: 2.0, False: 4.0}
 
     def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3,
                  concurrent=True, pipeline=False):
@@ -38,14 +43,18 @@ class GraphedKDStep:
         # fork/join inside the captured graph: the teacher's forward runs beside the student's, and the weight
         # gradients beside the dgrad / normalisation chain (many of these kernels fill < 256 CUs on their own)
         self.teacher_stream = torch.cuda.Stream() if (concurrent or pipeline) else None
-        # ... with several weight gradients in flight, each sized for its share of the CUs: the same k-loop work
+        # ... with several weight gradients in flight, each sized for a share of the CUs: the same k-loop work
         # with proportionally fewer atomic dW-tile flushes (measured: 1 -> 4 streams = +8 % on the step)
-        nside = self.WGRAD_STREAMS
+        # (KD6D_WGRAD_STREAMS / KD6D_WGRAD_BUDGET_DIV: tuning aids.  Swept on the closing state of round 1, medians of
+        #  3 runs: 4 streams at CUs/4 4539 images/s, CUs/3 4566, CUs/2 4595-4640, CUs/1.5 4597, whole device 4529;
+        #  3 streams 4330-4430, 5 streams 4140-4200, 6-8 streams 4340)
+        nside = int(os.environ.get("KD6D_WGRAD_STREAMS", self.WGRAD_STREAMS))
+        budget_div = float(os.environ.get("KD6D_WGRAD_BUDGET_DIV", self.WGRAD_BUDGET_DIV[bool(pipeline)]))
         snet = student.net
         snet.side_stream = torch.cuda.Stream() if concurrent else None
         snet.side_streams = ([snet.side_stream] + [torch.cuda.Stream() for _ in range(nside - 1)]
                              if concurrent and nside > 1 else None)
-        snet.wgrad_cu_budget = (ops.device_cu_count() // nside) if concurrent and nside > 1 else 0
+        snet.wgrad_cu_budget = int(ops.device_cu_count() / budget_div) if concurrent and nside > 1 else 0
         self.w_cls, self.w_reg, self.w_kd = (float(w) for w in loss_weights)
         self._w = None                                     # the same weights as a device tensor
         self.cfg_kd = cfg_kd
