@@ -225,7 +225,8 @@ class BatchNorm:
 
 class ConvBlock:
     """conv(no bias) + BN + LeakyReLU(0.1)  (backbone/common.py:250-324)."""
-    FUSE_STATS_MAX_ROWS = 1 << 15      # up to 256 workgroups adding into one channel; beyond that a separate pass wins
+    # up to 256 workgroups adding into one channel; beyond that a separate pass wins (KD6D_FUSE_STATS_ROWS: tuning aid)
+    FUSE_STATS_MAX_ROWS = int(os.environ.get("KD6D_FUSE_STATS_ROWS", 1 << 15))
 
     @staticmethod
     def bwd_replicas(rows):
