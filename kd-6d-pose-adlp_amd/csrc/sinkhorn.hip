@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
     const int* __restrict__ s_cnt, const float* __restrict__ yt, const float* __restrict__ beta,
     const int* __restrict__ t_start, const int* __restrict__ t_cnt,
     float blur, float scaling, float reach, float* __restrict__ loss_img, int* __restrict__ valid_img,
-    float* __restrict__ gx_out, float* __restrict__ galpha_out) {
+    float* __restrict__ gx_out, float* __restrict__ galpha_out, int slow_path) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   WaveLds* all = reinterpret_cast<WaveLds*>(smem_raw);
   float* red = reinterpret_cast<float*>(smem_raw + sizeof(WaveLds) * kWaves);  // [kWaves][5]
@@ -159,6 +159,102 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
     s_lam[i] = unbalanced ? (float)(1.0 / (1.0 + e / rho)) : 1.f;
   }
   __syncthreads();
+
+  // ---- small sets (N, M <= 16: the KD step has ~10 cells per image): the four softmins of an update run side by
+  // side on the four 16-lane rows of the wave instead of one after the other on 10 of its 64 lanes.  Same
+  // lse_row, same column order, same update formulas as the general path below: identical gradients (the loss
+  // value differs in the last bits, its ~20 terms are summed in another order).
+  if (N <= 16 && M <= 16 && !slow_path) {
+    const int grp = lane >> 4, idx = lane & 15;
+    const bool on_x = grp < 2;                        // rows of x (a_x, b_x) / rows of y (b_y, a_y)
+    const bool from_x = grp == 0 || grp == 3;         // softmin over the x points / over the y points
+    const int n_rows = on_x ? N : M, n_cols = from_x ? N : M;
+    const bool act = idx < n_rows;
+    const float* cxs = from_x ? L.px : L.qx;
+    const float* cys = from_x ? L.py : L.qy;
+    const float* logw = on_x ? L.la : L.lb;
+    float* pot = grp == 0 ? L.ax : grp == 1 ? L.bx : grp == 2 ? L.by : L.ay;          // potential this row owns
+    float* hself = grp == 0 ? L.hx1 : grp == 1 ? L.hx2 : grp == 2 ? L.hy1 : L.hy2;    // log weight + own potential / eps
+    const float* hcol = grp == 0 ? L.hx1 : grp == 1 ? L.hy2 : grp == 2 ? L.hy1 : L.hx2;
+    const float rx = act ? (on_x ? L.px[idx] : L.qx[idx]) : 0.f;
+    const float ry = act ? (on_x ? L.py[idx] : L.qy[idx]) : 0.f;
+    float g0, g1;
+    {
+      const double eps = eps_at(0);
+      const float lam = unbalanced ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
+      const float feps = (float)eps, inv = (float)(1.0 / eps);
+      if (act) pot[idx] = -lam * feps * lse_row<false>(rx, ry, cxs, cys, from_x ? L.la : L.lb, n_cols, inv, g0, g1);
+    }
+    __syncthreads();
+    for (int it = 0; it < n_eps; ++it) {
+      float lam, feps, inv;
+      if (it < kSched) {
+        lam = s_lam[it]; feps = s_feps[it]; inv = s_inv[it];
+      } else {
+        const double e = eps_at(it);
+        lam = unbalanced ? (float)(1.0 / (1.0 + e / rho)) : 1.f;
+        feps = (float)e; inv = (float)(1.0 / e);
+      }
+      if (act) hself[idx] = logw[idx] + pot[idx] * inv;
+      __syncthreads();
+      if (act) {
+        const float t = -lam * feps * lse_row<false>(rx, ry, cxs, cys, hcol, n_cols, inv, g0, g1);
+        pot[idx] = 0.5f * (pot[idx] + t);
+      }
+      __syncthreads();
+    }
+    const double eps = eps_at(n_eps - 1);
+    const float lam = unbalanced ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
+    const float feps = (float)eps, inv = (float)(1.0 / eps);
+    if (act) hself[idx] = logw[idx] + pot[idx] * inv;
+    __syncthreads();
+    const float w_unb = (float)(rho + 0.5 * eps);
+    const float inv_rho = unbalanced ? (float)(1.0 / rho) : 0.f;
+    float gr0 = 0.f, gr1 = 0.f;
+    float val = 0.f;
+    if (act) {
+      if (on_x) val = -lam * feps * lse_row<true>(rx, ry, cxs, cys, hcol, n_cols, inv, gr0, gr1);
+      else val = -lam * feps * lse_row<false>(rx, ry, cxs, cys, hcol, n_cols, inv, g0, g1);
+    }
+    // lanes idx (a_x / b_y) and idx + 16 (b_x / a_y) hold the two halves of a row's result
+    const float o_val = __shfl_xor(val, 16, 64), o_g0 = __shfl_xor(gr0, 16, 64), o_g1 = __shfl_xor(gr1, 16, 64);
+    float part = 0.f;
+    if (grp == 0 && act) {
+      const float a_x = val, b_x = o_val, gxx0 = gr0, gxx1 = gr1, gxy0 = o_g0, gxy1 = o_g1;
+      const float a = alpha[(size_t)(s0 + idx) * 8 + k];
+      float dS_da, gx0, gx1;
+      if (unbalanced) {
+        const float ea = expf(-a_x * inv_rho), eb = expf(-b_x * inv_rho);
+        dS_da = w_unb * (ea - eb);
+        const float c = -a * w_unb * inv_rho * lam;
+        gx0 = c * (ea * gxx0 - eb * gxy0);
+        gx1 = c * (ea * gxx1 - eb * gxy1);
+      } else {
+        dS_da = b_x - a_x;
+        gx0 = a * (gxy0 - gxx0);
+        gx1 = a * (gxy1 - gxx1);
+      }
+      part = a * dS_da;
+      gx_out[((size_t)(s0 + idx) * 8 + k) * 2 + 0] = gx0;
+      gx_out[((size_t)(s0 + idx) * 8 + k) * 2 + 1] = gx1;
+      galpha_out[(size_t)(s0 + idx) * 8 + k] = dS_da;
+    } else if (grp == 2 && act) {
+      const float b_y = val, a_y = o_val;
+      const float w = beta[(size_t)(t0 + idx) * 8 + k];
+      if (unbalanced) part = w * w_unb * (expf(-b_y * inv_rho) - expf(-a_y * inv_rho));
+      else part = w * (a_y - b_y);
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[wave * 5 + 4] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int w = 0; w < kWaves; ++w) tot += red[w * 5 + 4];
+      loss_img[b] = tot;
+      valid_img[b] = 1;
+    }
+    return;
+  }
 
   // ---- initialisation at eps_0 -------------------------------------------------
   {
@@ -300,9 +396,12 @@ extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, co
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  // KD6D_SINKHORN_LANES=0: every set on the general (one softmin after the other) path; read per call (tests)
+  const char* lanes_env = getenv("KD6D_SINKHORN_LANES");
+  const int slow = lanes_env && lanes_env[0] == '0';
   hipLaunchKernelGGL(sinkhorn_small_kernel, dim3(n_images), dim3(64 * kWaves), lds, st, xs, alpha,
                      s_start, s_cnt, yt, beta, t_start, t_cnt, blur, scaling, reach, loss_img, valid_img, grad_xs,
-                     grad_alpha);
+                     grad_alpha, slow);
   KD6D_CHECK_LAUNCH("kd6d_sinkhorn_div_fwd_bwd");
   return KD6D_OK;
 }

@@ -677,13 +677,17 @@ def test_pool_upsample_eltwise(gpu_device, dtype):
 
 
 @pytest.mark.parametrize("reach", [0.5, None])
-def test_sinkhorn_kernel_vs_oracle(gpu_device, reach):
-    """fp32 kernel vs fp64 oracle: loss rtol 1e-4, grads rtol 2e-3."""
+@pytest.mark.parametrize("lanes", ["1", "0"])
+def test_sinkhorn_kernel_vs_oracle(gpu_device, monkeypatch, reach, lanes):
+    """fp32 kernel vs fp64 oracle: loss rtol 1e-4, grads rtol 2e-3.  lanes "1": sets of up to 16
+    points run their four softmins side by side on the wave's four 16-lane rows (the 20 / 17-point images still take
+    the general path); "0": the general path for every image."""
     ops = _ops()
+    monkeypatch.setenv("KD6D_SINKHORN_LANES", lanes)
     from oracle.sinkhorn_ref import kd_loss_images
     r = np.random.default_rng(0)
-    counts_s = [10, 0, 9, 12, 1, 10]
-    counts_t = [10, 7, 0, 9, 3, 10]
+    counts_s = [10, 0, 9, 12, 1, 10, 20, 16, 3]
+    counts_t = [10, 7, 0, 9, 3, 10, 11, 16, 17]
     P, M = sum(counts_s), sum(counts_t)
     # LINEMOD-like: clustered votes around 8 keypoints, normalised coordinates
     centres = r.uniform(0.3, 0.7, (8, 2))
