@@ -187,6 +187,9 @@ def main():
         elapsed = float(t.item())
     losses = {k: float(v) for k, v in ld.items()}
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
+    # the one-launch BN / GN backward kernels wait at in-kernel barriers with a bounded spin: a wait that gave up
+    # means wrong gradients in the timed steps, so the run is invalid (reported in the JSON line, non-zero exit)
+    barrier_timeouts = int(ops.lib.kd6d_barrier_timeouts())
     if args.timeline and gstep is not None and rank == 0:
         buf, slots = ops.marks_end()
         t = buf.cpu().tolist()
@@ -261,7 +264,8 @@ def main():
                               ", frozen teacher run once per %d incoming batches (%d images) on its own stream, "
                               "student steps on single batches" % (gstep.G, gstep.G * B))),
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
-               "losses_last_step": losses, "finite": finite, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+               "losses_last_step": losses, "finite": finite, "barrier_timeouts": barrier_timeouts,
+               "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
                "host_issue_ms_idle_gpu": min(t_issue) * 1e3,
                "roofline": roof}
         # ---- CPU baseline leg (oracle = port of the reference step), rank 0, N=1 only ----
@@ -270,8 +274,12 @@ def main():
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    barrier_timeouts = max(barrier_timeouts, int(ops.lib.kd6d_barrier_timeouts()))
     if rank == 0:
+        out["barrier_timeouts"] = barrier_timeouts
         print(json.dumps(out))
+    if barrier_timeouts != 0 or not finite:
+        raise SystemExit("bench.py: INVALID run (barrier_timeouts=%d, finite=%s)" % (barrier_timeouts, finite))
 
 
 def write_layer_table(path, rec, n_instr):

@@ -219,6 +219,8 @@ class GraphedKDStep:
         self.opt.advance()
         self.g_opt.replay()
         self._count_opt_step()
+        for _, bn in self.student.net.bns:     # what FusedClipAdamW.launch() does when it runs from Python: the
+            bn.fold = None                     # cached eval-mode BN scale/shift belong to the previous weights
         return self.losses
 
     # ---- public -------------------------------------------------------------------------------

@@ -161,6 +161,11 @@ class PoseModuleKD(nn.Module):
         return out
 
     def train(self, mode=True):
+        if bool(mode) != bool(self.net.training):
+            # eval-mode BatchNorm scale/shift are cached per weight load; a replayed optimiser graph changes the
+            # weights without passing through Python, so the cache is dropped at every mode switch
+            for _, bn in self.net.bns:
+                bn.fold = None
         super().train(mode)
         self.net.training = mode
         return self

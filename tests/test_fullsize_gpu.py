@@ -1,0 +1,289 @@
+"""Parity at the sizes BASELINE.json is quoted on (config 2: B = 16, 256x256 DZI crops, darknet53 -> darknet_tiny_h),
+through the launch mode bench.py times (GraphedKDStep(pipeline=True): 2 hipGraphs per step, the teacher of batch k+1
+beside the student step of batch k), against oracle/kd_step_ref.py on the same seeded inputs.
+
+At this size the per-layer dispatcher picks kernels the B = 2 / 128x128 cases of test_step_gpu.py never reach inside a
+whole step (192x128 / 256x128 halo tiles, the LDS-DMA ring with split-K, the resident-patch kernel at 2^20 pixels,
+the one-launch BatchNorm backward's size switch, 8 replica rows): the first half of this file runs every convolution
+of the step at its benchmark shape against torch's CPU convolution, the second half the whole replayed step.
+
+Measured deviations are appended to gpurun_out/fullsize_parity.json when that directory exists (DESIGN.md section 6
+quotes them; the bf16 thresholds below are <= 2x what was measured).
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_step_gpu import build, ref_to_packed_rows
+from util_pack import pack_levels, round_to, unpack_levels, w_to_dgrad, w_to_krsc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+BIAS = [1.0] + [-6.0] * 14
+
+
+def _record(key, value):
+    d = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(d):
+        return
+    path = os.path.join(d, "fullsize_parity.json")
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[key] = value
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# every convolution of the benchmarked step, at its benchmark shape (B = 16), bf16, vs torch CPU
+# ---------------------------------------------------------------------------------------------------------
+def _layers():
+    import step_layers as BC
+    return [("teacher",) + l for l in BC.TEACHER] + [("student",) + l for l in BC.STUDENT]
+
+
+LAYERS = _layers()
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[1] for l in LAYERS])
+def test_conv_layer_at_benchmark_shape(gpu_device, layer):
+    """fwd (both networks), dgrad and wgrad (student) of one layer of the step at B = 16: bf16-representable inputs,
+    fp32 results -> only the fp32 summation order differs from torch's CPU convolution (2e-4), plus one bf16
+    rounding where the kernel stores bf16 (1.2e-2).  The engine's own workspace size makes the few-tile / long-K
+    layers take the split-K path exactly as in the step."""
+    from kd6d import ops
+    from kd6d.engine import PoseNet
+    net, name, cin, cout, k, stride, levels = layer
+    B = 16
+    dev = gpu_device
+    dtype = torch.bfloat16
+    pad = k // 2
+    g = torch.Generator().manual_seed(len(name) * 131 + cin + cout)
+    geom = ops.Geom(B, cin, cout, k, stride, pad, levels)
+    xs = [round_to(torch.randn(B, cin, h, w, generator=g), dtype) for (h, w) in levels]
+    w = round_to(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dtype)
+    ws = torch.empty(PoseNet.WORKSPACE_BYTES // 4, dtype=torch.float32, device=dev)
+    xp = pack_levels(xs, dtype).to(dev)
+    y = ops.conv2d_fwd(geom, xp, w_to_krsc(w, dtype).to(dev), out_f32=True, workspace=ws)
+    torch.cuda.synchronize()
+    refs = [F.conv2d(x, w, stride=stride, padding=pad) for x in xs]
+    for gl, ref in zip(unpack_levels(y.cpu(), B, geom.levels_out), refs):
+        torch.testing.assert_close(gl, ref, rtol=2e-4, atol=2e-4)
+    if net != "student":
+        return
+    dys = [round_to(torch.randn(B, cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
+    dyp = pack_levels(dys, dtype).to(dev)
+    dx = ops.conv2d_dgrad(geom, dyp, w_to_dgrad(w, dtype).to(dev))
+    dw = torch.zeros(cout, k, k, cin, dtype=torch.float32, device=dev)
+    dw_half = torch.zeros_like(dw)
+    ops.conv2d_wgrad(geom, xp, dyp, dw)
+    ops.conv2d_wgrad(geom, xp, dyp, dw_half, cu_budget=128)      # the pipelined step sizes forked launches for CUs / 2
+    torch.cuda.synchronize()
+    ref_w = torch.zeros(cout, cin, k, k)
+    for (h, w_), x, dy, gl in zip(levels, xs, dys, unpack_levels(dx.cpu(), B, levels)):
+        ref = torch.nn.grad.conv2d_input((B, cin, h, w_), w, dy, stride=stride, padding=pad)
+        torch.testing.assert_close(gl, ref, rtol=1.2e-2, atol=1.2e-2)
+        ref_w += torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dy, stride=stride, padding=pad)
+    scale = max(float(ref_w.abs().max()), 1.0)
+    for got in (dw, dw_half):
+        torch.testing.assert_close(got.cpu().permute(0, 3, 1, 2), ref_w, rtol=2e-4, atol=2e-4 * scale)
+    assert ops.lib.kd6d_barrier_timeouts() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the whole step, replayed the way bench.py replays it
+# ---------------------------------------------------------------------------------------------------------
+def _grad_report(student, ref_grads, clip, gn_ref):
+    got = {k: p.grad.detach().float().cpu() for k, p in student.named_parameters() if p.grad is not None}
+    dev_norm, dev_elem, num, den = {}, {}, 0.0, 0.0
+    for k, g in ref_grads.items():
+        r = g / clip
+        rn = float(r.norm())
+        dev_norm[k] = abs(float(got[k].norm()) - rn) / max(rn, 1e-6 * gn_ref)
+        dev_elem[k] = float((got[k] - r).norm()) / max(rn, 1e-6 * gn_ref)
+        num += dev_norm[k] * rn ** 2
+        den += rn ** 2
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in got.values())))
+    cos = float(sum((got[k].double() * (ref_grads[k] / clip).double()).sum() for k in ref_grads)) / (total * gn_ref)
+    return dict(worst_norm=max(dev_norm.values()), worst_norm_name=max(dev_norm, key=dev_norm.get),
+                wmean_norm=num / den, total=abs(total - gn_ref) / gn_ref, cosine=cos,
+                worst_elem=max(dev_elem.values()), worst_elem_name=max(dev_elem, key=dev_elem.get))
+
+
+# precision -> (losses cls/reg rel, kd rel, grad norm rel, per-tensor norm worst, weighted mean, 1 - cosine,
+#               second-step losses rel, sign agreement of the first AdamW update)
+TOL = {
+    "fp32": dict(loss=1e-3, kd=2e-3, gn=5e-3, worst=3e-2, wmean=1e-3, cos=1e-4, loss2=2e-2, sign=0.995),
+    "bf16": dict(loss=3e-2, kd=0.2, gn=8e-2, worst=0.5, wmean=6e-2, cos=3e-2, loss2=0.1, sign=0.90),
+}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("arch,mixed", [("darknet_tiny_h", False), ("darknet_tiny", True)],
+                         ids=["config2_ape_tinyh", "config4_13class_tiny"])
+def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed):
+    """BASELINE config 2 (Ape, 53 -> tiny_h) and config 4's per-GPU shard (the 13 LINEMOD classes mixed in one batch,
+    53 -> tiny), B = 16, 256x256, through GraphedKDStep(pipeline=True): losses, global and per-tensor gradient norms,
+    gradient direction, the first fused clip + AdamW update and the losses of the following step vs the oracle."""
+    from kd6d import ops
+    from kd6d.graph import GraphedKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import INTERNAL_K, MESH_DIAMETERS, make_batch
+    from oracle import kd_step_ref as O
+    dev = gpu_device
+    B, crop = 16, 256
+    tol = TOL[precision]
+    teacher = build("darknet53", precision, 2, dev, BIAS).eval()
+    student = build(arch, precision, 1, dev).train()
+    opt = FusedClipAdamW(student, lr=1e-3, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 10100, pct_start=0.05, cycle_momentum=False,
+                                                anneal_strategy="linear")
+    ref = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0, teacher_cls_bias=BIAS)
+    levels = [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
+    cells = sum(h * w for h, w in levels)
+    counts = [h * w for h, w in levels]
+    keys_ref = torch.rand(B * cells, generator=torch.Generator().manual_seed(17))
+    student._debug_keys = keys_ref[ref_to_packed_rows(B, levels)].to(dev)
+
+    def choose(vp, n, im, l, g):
+        off = im * cells + sum(counts[:l])
+        return torch.argsort(keys_ref[off + vp], stable=True)[:n]
+
+    cpu_batches, batches = [], []
+    for i in range(2):
+        images, targets = make_batch(B, 41 + i, crop=crop, mixed_classes=mixed)
+        cpu_batches.append((images.tensors, [t.as_dict() for t in targets]))
+        batches.append((ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)))
+    if mixed:
+        assert len({int(t["class_ids"][0]) for t in cpu_batches[0][1]}) == 13
+
+    gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=True)
+    p0 = student.net.store.params.detach().cpu().clone()
+    assert gs(*batches[0]) is None                          # priming call: teacher(0)
+    ld = gs(*batches[1])                                    # teacher(1) beside the student step on batch 0 (captures)
+    torch.cuda.synchronize()
+    got1 = {k: float(v) for k, v in ld.items()}
+    gn1 = float(opt.grad_norm())
+    # oracle, step 1
+    res1 = ref.step(*cpu_batches[0], choose=choose)
+    ref_grads = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
+    clip = min(1.0, 1.0 / (res1["grad_norm"] + 1e-6))
+    rep = _grad_report(student, ref_grads, clip, res1["grad_norm"])
+    rep.update({"d_" + k: abs(got1[k] - res1[k]) / max(abs(res1[k]), 1e-6) for k in got1},
+               d_grad_norm=abs(gn1 - res1["grad_norm"]) / res1["grad_norm"], losses=got1, oracle=res1)
+    # first AdamW update: -lr * sign(g) where |g| is well above eps; compare the direction of travel element-wise
+    sd_ref = ref.student.state_dict()
+    sd_got = student.state_dict()
+    agree = count = 0
+    for k, g in ref_grads.items():
+        big = (g.abs() > 1e-3 * g.abs().max()).reshape(-1)
+        if k not in sd_got or not bool(big.any()):
+            continue
+        d_got = (sd_got[k].cpu() - _initial(student, p0, k)).reshape(-1)[big]
+        agree += int((torch.sign(d_got) == -torch.sign(g.reshape(-1)[big])).sum())
+        count += int(big.sum())
+    rep["sign_agreement"] = agree / max(count, 1)
+    # second call: the student step on batch 1 with the updated weights
+    sched.step()
+    ld2 = gs(*batches[0])
+    torch.cuda.synchronize()
+    got2 = {k: float(v) for k, v in ld2.items()}
+    res2 = ref.step(*cpu_batches[1], choose=choose)
+    rep.update({"d2_" + k: abs(got2[k] - res2[k]) / max(abs(res2[k]), 1e-6) for k in got2})
+    rep["barrier_timeouts"] = int(ops.lib.kd6d_barrier_timeouts())
+    _record("%s_%s" % (arch + ("_mixed13" if mixed else ""), precision), rep)
+    print("[fullsize %s %s] %s" % (arch, precision, json.dumps(rep, default=str)))
+
+    assert rep["barrier_timeouts"] == 0
+    assert res1["loss_kd"] > 0, "the KD term must be active"
+    assert rep["d_loss_cls"] <= tol["loss"] and rep["d_loss_reg"] <= tol["loss"], rep
+    assert rep["d_loss_kd"] <= tol["kd"], rep
+    assert rep["d_grad_norm"] <= tol["gn"] and rep["total"] <= tol["gn"], rep
+    assert rep["worst_norm"] <= tol["worst"] and rep["wmean_norm"] <= tol["wmean"], rep
+    assert 1.0 - rep["cosine"] <= tol["cos"], rep
+    assert rep["sign_agreement"] >= tol["sign"], rep
+    assert rep["d2_loss_cls"] <= tol["loss2"] and rep["d2_loss_reg"] <= tol["loss2"], rep
+    assert opt.steps == 2
+
+
+def _initial(student, p0, key):
+    """Logical-shape view of parameter `key` inside a CPU copy of the flat buffer taken before training."""
+    st = student.net.store
+    if key.startswith("head.scales."):
+        l = int(key.split(".")[2])
+        b = st.base(st.entries["head.scales"])
+        return p0[b + l:b + l + 1]
+    e = st.entries[key]
+    b = st.base(e)
+    flat = p0[b:b + e.numel]
+    if e.kind == "conv":
+        co, ci, kh, kw = e.shape
+        cop, _, _, cip = e.store_shape
+        return flat.view(cop, kh, kw, cip)[:co, :, :, :ci].permute(0, 3, 1, 2)
+    return flat.view(e.store_shape)[tuple(slice(0, d) for d in e.shape)]
+
+
+def test_config1_plumbing_kd_weight_zero(gpu_device):
+    """BASELINE config 1 on the GPU: configs/ape.yaml, darknet_tiny student, kd_weight = 0, batch = 1.  A teacher with
+    the reference's prior bias emits no cell above 0.1, so loss_kd = 0 (kd_loss.py:102-103) and the term is dropped
+    from the total (train_kd.py:131-135): the update must equal the oracle's with kd_weight = 0, in both launch modes."""
+    from kd6d.graph import GraphedKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import INTERNAL_K, MESH_DIAMETERS, make_batch
+    from oracle import kd_step_ref as O
+    dev = gpu_device
+    B, crop, arch = 1, 256, "darknet_tiny"
+    images, targets = make_batch(B, 5, crop=crop)
+    quiet = [-12.0] * 15      # no teacher cell passes the 0.1 threshold, like a teacher with the reference's prior bias
+    ref = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=0.0, teacher_cls_bias=quiet)
+    levels = [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
+    cells = sum(h * w for h, w in levels)
+    counts = [h * w for h, w in levels]
+    keys_ref = torch.rand(B * cells, generator=torch.Generator().manual_seed(2))
+
+    def choose(vp, n, im, l, g):
+        off = im * cells + sum(counts[:l])
+        return torch.argsort(keys_ref[off + vp], stable=True)[:n]
+
+    res = ref.step(images.tensors, [t.as_dict() for t in targets], choose=choose)
+    ref_grads = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
+    clip = min(1.0, 1.0 / (res["grad_norm"] + 1e-6))
+    assert res["loss_kd"] == 0.0
+    img = ImageList(images.tensors.to(dev), images.sizes)
+    tgt = PackedTargets(targets, dev)
+    for mode in ("eager", "graph"):
+        teacher = build("darknet53", "fp32", 2, dev, quiet).eval()
+        student = build(arch, "fp32", 1, dev).train()
+        student._debug_keys = keys_ref[ref_to_packed_rows(B, levels)].to(dev)
+        opt = FusedClipAdamW(student, lr=1e-3)
+        if mode == "eager":
+            student.zero_grad()
+            with torch.no_grad():
+                pred_t = teacher(img, targets=tgt, is_teacher=True)
+            assert pred_t["post_pos_per_img"] == [0]
+            _, ld = student(img, targets=tgt, pred_t=pred_t)
+            loss = (ld["loss_cls"] * 0.1).mean() + (ld["loss_reg"] * 1.0).mean()     # w_kd == 0: the term is not added
+            loss.backward()
+            opt.step()
+        else:
+            ld = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 0.0))(img, tgt)
+        torch.cuda.synchronize()
+        assert float(ld["loss_kd"]) == 0.0
+        assert float(ld["loss_cls"]) == pytest.approx(res["loss_cls"], rel=1e-3)
+        assert float(ld["loss_reg"]) == pytest.approx(res["loss_reg"], rel=1e-3)
+        assert float(opt.grad_norm()) == pytest.approx(res["grad_norm"], rel=5e-3)
+        rep = _grad_report(student, ref_grads, clip, res["grad_norm"])
+        assert rep["worst_norm"] <= 3e-2 and rep["wmean_norm"] <= 1e-3 and 1 - rep["cosine"] <= 1e-4, (mode, rep)

@@ -80,7 +80,7 @@ def sample(flat_levels_tensor):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["step_tinyh_b2_128", "step_tiny_b2_128"])
+@pytest.mark.parametrize("name", ["step_tinyh_b2_128", "step_tiny_b2_128", "step_tinyh_b2_256"])
 def test_step_against_reference_golden(gpu_device, name, precision):
     from kd6d.kd_losses import PackedTargets
     from kd6d.libs.poses import ImageList
@@ -435,3 +435,42 @@ def test_grouped_teacher_matches_eager_steps(gpu_device):
     np.testing.assert_allclose(h_g[1:, :3], h_e[1:, :3], rtol=0.1)
     d_e, d_g = np.abs(p_e - p0), np.abs(p_g - p0)
     assert abs(d_g.mean() / d_e.mean() - 1.0) < 0.02
+
+
+def test_eval_between_graph_replays_sees_current_weights(gpu_device):
+    """A replayed optimiser graph changes the weights without passing through Python: the eval-mode BatchNorm
+    scale/shift cached by the previous validation must not survive it (every VAL_FREQ steps train_kd.py validates
+    between replays).  The eval forward after further replays equals the eval forward of a fresh module loaded with
+    the current state_dict, bit for bit."""
+    from kd6d.graph import GraphedKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import make_batch
+    dev = gpu_device
+    B, crop, arch = 2, 64, "darknet_tiny_h"
+    teacher = build("darknet53", "fp32", 2, dev, [1.0] + [-6.0] * 14).eval()
+    student = build(arch, "fp32", 1, dev).train()
+    opt = FusedClipAdamW(student, lr=1e-2)
+    images, targets = make_batch(B, 10, crop=crop)
+    img, tgt = ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)
+    gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0))
+
+    def eval_logits(m):
+        m.eval()
+        cls, reg = m.net.forward(img.tensors)
+        out = (cls.clone(), reg.clone())
+        m.train()
+        return out
+
+    gs(img, tgt)
+    first = eval_logits(student)
+    for _ in range(3):
+        gs(img, tgt)
+    second = eval_logits(student)
+    fresh = build(arch, "fp32", 1, dev)
+    fresh.load_state_dict(student.state_dict())
+    want = eval_logits(fresh)
+    torch.cuda.synchronize()
+    assert not torch.equal(first[0], second[0]), "the replayed steps did not train"
+    assert torch.equal(second[0], want[0]) and torch.equal(second[1], want[1])

@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from kd6d.arguments.argument_kd import get_args  # noqa: E402
+from kd6d._lib import lib  # noqa: E402
 from kd6d.kd_losses import PackedTargets  # noqa: E402
 from kd6d.libs.distributed import get_rank, shard_batch, synchronize  # noqa: E402
 from kd6d.libs.eval_libs import valid  # noqa: E402
@@ -148,6 +149,13 @@ if __name__ == "__main__":
             print("steps: %d/%d, lr:%.6f, cls:%.4f, reg:%.4f, kd:%.4f  (%.1f img/s)" % (
                 total_steps, cfg["SOLVER"]["MAX_ITER"], optimizer.param_groups[0]["lr"], float(loss_cls),
                 float(loss_reg), float(loss_kd), idx * cfg["SOLVER"]["IMS_PER_BATCH"] / max(dt, 1e-9)))
+        if total_steps % 50 == 0 or total_steps % VAL_FREQ == 0:
+            # in-kernel barriers of the one-launch BN / GN backward give up after a bounded spin instead of hanging
+            # the GPU; a wait that gave up means wrong gradients, so training stops
+            n_to = lib.kd6d_barrier_timeouts()
+            if n_to != 0:
+                raise SystemExit("kd6d: %d in-kernel barrier waits timed out (gradients of a step are wrong); "
+                                 "re-run with KD6D_BN_ONEPASS=0 KD6D_GN_ONEPASS=0" % n_to)
         if get_rank() == 0 and total_steps % VAL_FREQ == 0:
             acc = valid(cfg, total_steps, valid_loader, model, device, valid_meshes)     # train_kd.py:148-150
             model.train()
