@@ -116,8 +116,9 @@ def main():
     student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
     student.net.reset_parameters(seed=1)
     student = student.to(dev).train()
+    route = D.init_exchange() if use_pg else "none"      # kd6d_comm_* over librccl (include/kd6d.h)
     if use_pg:
-        dist.broadcast(student.net.store.params, 0)
+        D.broadcast_(student.net.store.params, 0)
         student.net.invalidate()
     base_lr = 1e-3 / world                      # libs/train_libs.py:117
     opt = FusedClipAdamW(student, lr=base_lr, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
@@ -181,10 +182,15 @@ def main():
     if use_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    rccl_ranks = 1
     if use_pg:
+        rccl_ranks = dist.get_world_size()
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(rccl_ranks)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        elapsed = max(float(x.item()) for x in every)          # the contract's MAX over ranks
     losses = {k: float(v) for k, v in ld.items()}
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
     # the one-launch BN / GN backward kernels wait at in-kernel barriers with a bounded spin: a wait that gave up
@@ -251,13 +257,13 @@ def main():
                                 "ms_per_step": v[2] / n_instr} for k, v in by_kind.items()},
                 "step_algorithmic_tflops": (value * flop_img / 1e12) if flop_img else None}
         out = {"metric": "KD train-step images/sec (teacher+student fwd + OT loss + bwd + AdamW)", "value": value,
-               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "unit": "images/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": per_rank_ms, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                "data": "synthetic",
                "config": {"workload": "Ape KD: darknet53 teacher -> %s student, kd_weight=5, %s, batch=%d/GPU, "
                                       "%s" % (args.student, args.precision, B,
                                               "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
-                          "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "global_batch": B * world, "parallelism": "dp%d" % world, "exchange": route,
                           "launch": "eager" if gstep is None else ("hipGraph replay (2 graphs/step)" + (
                               "" if not gstep.pipeline else
                               ", teacher(k+1) overlapped with student step(k)" if not hasattr(gstep, "G") else
@@ -273,6 +279,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, B, full)
     if use_pg:
         dist.barrier()
+        D.shutdown_exchange()
         dist.destroy_process_group()
     barrier_timeouts = max(barrier_timeouts, int(ops.lib.kd6d_barrier_timeouts()))
     if rank == 0:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 5
+#define KD6D_ABI_VERSION 6
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -327,6 +327,27 @@ int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_
                     double weight_decay, int64_t step, const float* hyper_dev, void* bf16_shadow, void* stream);
 int kd6d_set_hyper(float* hyper_dev, double lr, double beta1, double beta2, int64_t step, void* stream);
 int kd6d_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- data-parallel exchange over RCCL / xGMI: replaces the reference's process-group plumbing for the step --
+ * libs/distributed.py:9-41 (gloo rank / world / barrier helpers), train_kd.py:48-51 (init_process_group + barrier),
+ * the DDP constructor's one-time parameter broadcast (libs/train_libs.py:123-130) -- and adds the per-step gradient
+ * all-reduce the reference lacks (its DDP wrapper is discarded, libs/train_libs.py:130).
+ * One communicator per process (= per GPU, the current HIP device at kd6d_comm_init).  Rendezvous: rank 0 calls
+ * kd6d_comm_unique_id (128 bytes, host memory) and hands the id to the other ranks by any out-of-band channel
+ * (the Python host uses the torch.distributed store); every rank then calls kd6d_comm_init (collective).
+ * kd6d_comm_allreduce: in place, fp32, sum or mean over ranks, asynchronous on `stream` (stream-ordered behind
+ * the caller's last weight gradient: no host synchronisation).  kd6d_comm_broadcast: in place, raw bytes from
+ * `root`.  librccl is resolved at run time (a copy already mapped into the process is shared); without it these
+ * return KD6D_ERR_UNSUPPORTED and everything else in this header still works. */
+typedef struct kd6d_comm kd6d_comm;
+int kd6d_comm_unique_id(void* id_out_host /* 128 bytes */);
+int kd6d_comm_init(kd6d_comm** comm, int rank, int world, const void* unique_id_host /* 128 bytes */);
+int kd6d_comm_rank(const kd6d_comm* comm);
+int kd6d_comm_world(const kd6d_comm* comm);
+int kd6d_comm_version(void);      /* RCCL version code (e.g. 22703), -1 without librccl */
+int kd6d_comm_allreduce(kd6d_comm* comm, float* buf, int64_t n, int mean, void* stream);
+int kd6d_comm_broadcast(kd6d_comm* comm, void* buf, int64_t nbytes, int root, void* stream);
+int kd6d_comm_destroy(kd6d_comm* comm);
 
 #ifdef __cplusplus
 }

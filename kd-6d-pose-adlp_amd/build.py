@@ -58,7 +58,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(compile_one, _sources()))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -15,7 +15,7 @@ KD6D_F32 = 1
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 GN_STATS_READY, GN_WS_ZEROED = 1, 2
 MAX_SEG = 5
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Seg(ctypes.Structure):
@@ -97,6 +97,14 @@ SIGNATURES = {
     "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
     "kd6d_set_hyper": [_P, _D, _D, _D, _I64, _P],
     "kd6d_cast_f32_to_bf16": [_P, _P, _I64, _P],
+    "kd6d_comm_unique_id": [_P],
+    "kd6d_comm_init": [ctypes.POINTER(_P), _I, _I, _P],
+    "kd6d_comm_rank": [_P],
+    "kd6d_comm_world": [_P],
+    "kd6d_comm_version": [],
+    "kd6d_comm_allreduce": [_P, _P, _I64, _I, _P],
+    "kd6d_comm_broadcast": [_P, _P, _I64, _I, _P],
+    "kd6d_comm_destroy": [_P],
 }
 _RESTYPE = {"kd6d_last_error": ctypes.c_char_p}
 

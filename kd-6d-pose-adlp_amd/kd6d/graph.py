@@ -202,9 +202,7 @@ class GraphedKDStep:
         self._restore(snap)
 
     def _exchange(self):
-        if D.exchange_active():
-            st = self.student.net.store
-            D.allreduce_mean_(st.grads[:st.n_train])
+        D.exchange_gradients(self.student.net.store)
 
     def _count_opt_step(self):
         # torch's lr schedulers count optimizer.step() calls to warn about ordering

@@ -1,10 +1,14 @@
 """Process-group helpers with the reference's names (libs/distributed.py:9-41) plus the
 gradient exchange the reference lacks (its DDP wrapper is discarded, libs/train_libs.py:124-130).
 
-MI355X: one process per GPU, backend "nccl" (= RCCL over xGMI).  The data path has exactly one
-collective per step: a mean all-reduce of the single flat fp32 gradient bucket (2.3 M / 8.5 M
-elements) -- latency-bound at these sizes, so one bucket, no overlap machinery.
+MI355X: one process per GPU.  The data path has exactly one collective per step: a mean all-reduce
+of the single flat fp32 gradient bucket (2.3 M / 8.5 M elements) -- latency-bound at these sizes, so
+one bucket, no overlap machinery.  The collective goes through the C ABI (kd6d_comm_*: a communicator
+this library owns on librccl, include/kd6d.h), enqueued on the step's HIP stream between its two
+replayed graphs; torch.distributed is only the rendezvous (the 128-byte RCCL id travels over its
+store) and the fall-back route for CPU tensors (the gloo tests) or when librccl cannot be opened.
 """
+import ctypes
 import math
 import os
 
@@ -39,10 +43,72 @@ def exchange_active():
     return dist.get_world_size() > 1 or os.environ.get("KD6D_EXCHANGE_SINGLE_RANK") == "1"
 
 
+_comm = None            # kd6d_comm* of this process (ctypes.c_void_p) once init_exchange() succeeded
+_route = "none"
+
+
+def exchange_route():
+    """Which library carries the per-step collective: 'kd6d_comm (librccl x.y.z)', 'torch.distributed (<backend>)'
+    or 'none' (single process)."""
+    return _route
+
+
+def init_exchange():
+    """Collective (every rank calls it once, after init_process_group and torch.cuda.set_device): build this
+    process's kd6d communicator.  Rank 0 creates the RCCL id, the process group's store hands it out."""
+    global _comm, _route
+    if not exchange_active():
+        _route = "none"
+        return _route
+    _route = "torch.distributed (%s)" % dist.get_backend()
+    if _comm is not None or not torch.cuda.is_available():
+        return _route
+    from .._lib import lib
+    ident = ctypes.create_string_buffer(128)
+    ok = 1
+    if get_rank() == 0 and lib.kd6d_comm_unique_id(ident) != 0:
+        ok = 0
+    box = [ident.raw if ok else None]
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return _route            # rank 0 has no librccl: every rank stays on torch.distributed
+    handle = ctypes.c_void_p()
+    rc = lib.kd6d_comm_init(ctypes.byref(handle), get_rank(), dist.get_world_size(), box[0])
+    flags = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)       # all ranks take the same route
+    if int(flags.item()) == 1:
+        _comm = handle
+        v = lib.kd6d_comm_version()
+        _route = "kd6d_comm (librccl %d.%d.%d)" % (v // 10000, (v // 100) % 100, v % 100)
+    elif rc == 0:
+        lib.kd6d_comm_destroy(handle)
+    return _route
+
+
+def shutdown_exchange():
+    global _comm, _route
+    if _comm is not None:
+        from .._lib import lib
+        torch.cuda.synchronize()
+        lib.kd6d_comm_destroy(_comm)
+        _comm = None
+    _route = "none"
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
 def allreduce_mean_(flat):
-    """In-place mean over ranks of one flat bucket."""
+    """In-place mean over ranks of one flat bucket (asynchronous on the current HIP stream)."""
     n = get_world_size()
     if not exchange_active():
+        return flat
+    if _comm is not None and flat.is_cuda:
+        from .._lib import check, lib
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        check(lib.kd6d_comm_allreduce(_comm, ctypes.c_void_p(flat.data_ptr()), flat.numel(), 1, _stream()),
+              "kd6d_comm_allreduce")
         return flat
     if dist.get_backend() == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
@@ -52,8 +118,21 @@ def allreduce_mean_(flat):
     return flat
 
 
+def exchange_gradients(store):
+    """THE exchange step of the data-parallel path: mean over ranks of the trainable slice of the flat gradient
+    bucket.  Parameters the reference registers but never gives a gradient (backbone.output.*, head.scales.4 of a
+    4-level student) live behind n_train and stay out of the collective."""
+    if exchange_active():
+        allreduce_mean_(store.grads[:store.n_train])
+
+
 def broadcast_(flat, src=0):
-    if get_world_size() > 1:
+    if _comm is not None and flat.is_cuda and exchange_active():
+        from .._lib import check, lib
+        assert flat.is_contiguous()
+        check(lib.kd6d_comm_broadcast(_comm, ctypes.c_void_p(flat.data_ptr()), flat.numel() * flat.element_size(),
+                                      src, _stream()), "kd6d_comm_broadcast")
+    elif get_world_size() > 1:
         dist.broadcast(flat, src)
     return flat
 

@@ -251,5 +251,5 @@ class PoseModuleKD(nn.Module):
         net.backward(dcls, dreg)
         ops.mark("student.bwd.end")
         from ..libs import distributed as D
-        if D.exchange_active() and not getattr(self, "_defer_allreduce", False):
-            D.allreduce_mean_(st.grads[:st.n_train])      # GraphedKDStep issues it between its two graphs
+        if not getattr(self, "_defer_allreduce", False):   # GraphedKDStep issues it between its two graphs
+            D.exchange_gradients(st)

@@ -617,7 +617,9 @@ class KDStepRef:
         bt = torch.stack([t["bbox_trans"] for t in targets])
         return teacher_select(cls_t, reg_t, bt), (cls_t, reg_t)
 
-    def step(self, images, targets, choose=None, return_extras=False):
+    def forward_backward(self, images, targets, choose=None):
+        """train_kd.py:104-137: teacher, student, losses, weighting, backward.  Leaves the UNCLIPPED gradients in
+        p.grad (what one data-parallel rank contributes to the mean all-reduce)."""
         self.student.zero_grad()
         teacher = None
         extras = {}
@@ -633,12 +635,22 @@ class KDStepRef:
         if self.kd_weight > 0:
             loss = loss + out["loss_kd"] * self.kd_weight
         loss.backward()
+        extras.update(student_logits=(cls_s, reg_s), labels=labels, out=out)
+        return out, extras
+
+    def optimizer_step(self):
+        """train_kd.py:138-140 on whatever p.grad holds: clip_grad_norm_(1.0), AdamW, OneCycle.  Returns the
+        pre-clip global gradient norm."""
         gn = nn.utils.clip_grad_norm_(self.student.parameters(), 1.0)
         self.opt.step()
         self.sched.step()
+        return float(gn)
+
+    def step(self, images, targets, choose=None, return_extras=False):
+        out, extras = self.forward_backward(images, targets, choose)
+        gn = self.optimizer_step()
         res = dict(loss_cls=float(out["loss_cls"]), loss_reg=float(out["loss_reg"]),
-                   loss_kd=float(out["loss_kd"]), grad_norm=float(gn))
+                   loss_kd=float(out["loss_kd"]), grad_norm=gn)
         if return_extras:
-            extras.update(student_logits=(cls_s, reg_s), labels=labels, out=out)
             return res, extras
         return res

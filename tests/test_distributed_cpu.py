@@ -30,7 +30,17 @@ def _worker(rank, world, port, out):
     p = torch.full((64,), float(rank))
     D.broadcast_(p, 0)
     D.synchronize()
-    out[rank] = (g.clone(), p.clone())
+    # the exchange step GraphedKDStep._exchange / PoseModuleKD._run_backward drive: the trainable slice of the flat
+    # gradient bucket of a real parameter store; registered-but-unused parameters stay out of the collective
+    from kd6d import engine
+    st = engine.PoseNet("darknet_tiny_h", torch.float32).store
+    st.grads = torch.full((st.params.numel(),), float(rank + 1))       # oversize on purpose: [n_train:] must not move
+    assert D.exchange_route() in ("none", "torch.distributed (gloo)")
+    D.init_exchange()
+    assert D.exchange_route() == "torch.distributed (gloo)"
+    D.exchange_gradients(st)
+    frozen = sorted(e.name for e in st.order if e.region == "frozen")
+    out[rank] = (g.clone(), p.clone(), st.grads.clone(), st.n_train, frozen)
     dist.destroy_process_group()
 
 
@@ -42,9 +52,13 @@ def test_allreduce_mean_and_broadcast_world2():
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     exp = torch.arange(1000, dtype=torch.float32) * 1.5
     for r in range(world):
-        g, p = out[r]
+        g, p, bucket, n_train, frozen = out[r]
         assert torch.equal(g, exp)
         assert torch.equal(p, torch.zeros(64))
+        assert 2_200_000 < n_train < bucket.numel()
+        assert torch.equal(bucket[:n_train], torch.full((n_train,), 1.5))              # mean of rank gradients
+        assert torch.equal(bucket[n_train:], torch.full((bucket.numel() - n_train,), float(r + 1)))
+        assert frozen == ["backbone.output.final_conv.bias", "backbone.output.final_conv.weight", "head.scales.4.scale"]
 
 
 def test_single_process_helpers():

@@ -123,7 +123,11 @@ def _grad_report(student, ref_grads, clip, gn_ref):
 #               second-step losses rel, sign agreement of the first AdamW update)
 TOL = {
     "fp32": dict(loss=1e-3, kd=2e-3, gn=5e-3, worst=3e-2, wmean=1e-3, cos=1e-4, loss2=2e-2, sign=0.995),
-    "bf16": dict(loss=3e-2, kd=0.2, gn=8e-2, worst=0.5, wmean=6e-2, cos=3e-2, loss2=0.1, sign=0.90),
+    # measured on MI355X (round 2, gpurun_out/fullsize_parity.json -> DESIGN.md section 6), config 2 / config 4:
+    # loss_cls 4.9e-4 / 6.4e-4, loss_reg 1.4e-3 / 1.2e-3, loss_kd 2.9e-3 / 2.1e-2, global grad norm 2.7e-4 / 3.1e-4,
+    # per-tensor norm worst 0.25 / 0.20 (first-layer BatchNorm gains), weighted mean 8.5e-4 / 7.0e-4,
+    # 1 - cosine 4.8e-4 / 2.3e-4, second-step losses <= 1.5e-3 (kd 1.1e-2 / 2.1e-2), update-sign agreement 0.938 / 0.930
+    "bf16": dict(loss=3e-3, kd=4e-2, gn=1e-3, worst=0.5, wmean=2e-3, cos=1e-3, loss2=8e-3, sign=0.90),
 }
 
 

@@ -160,8 +160,12 @@ def test_step_against_reference_golden(gpu_device, name, precision):
         assert worst <= 2e-2 and wmean <= 1e-3, "per-parameter grad-norm deviation worst %.4f mean %.5f" % (worst, wmean)
         assert total == pytest.approx(gn_ref, rel=1e-2)
     else:
-        assert worst <= 0.5 and wmean <= 6e-2, (worst, wmean)
-        assert total == pytest.approx(gn_ref, rel=6e-2)
+        # measured (round 2): worst 0.24 / 0.23 at 128x128, 0.64 at 256x256 (a 64-element BatchNorm gain whose gradient
+        # is a cancelling sum over 131072 pixels of B = 2 images: positively homogeneous activations make the loss
+        # invariant to a common scale of the gains, what is left is rounding-sensitive; at B = 16 the same tensor is
+        # within 0.25, tests/test_fullsize_gpu.py); weighted mean <= 0.0038, global norm <= 0.0026
+        assert worst <= (1.3 if crop >= 256 else 0.5) and wmean <= 8e-3, (worst, wmean)
+        assert total == pytest.approx(gn_ref, rel=6e-3)
 
 
 def test_step_against_oracle_fp32_with_optimizer(gpu_device):
@@ -441,7 +445,7 @@ def test_eval_between_graph_replays_sees_current_weights(gpu_device):
     """A replayed optimiser graph changes the weights without passing through Python: the eval-mode BatchNorm
     scale/shift cached by the previous validation must not survive it (every VAL_FREQ steps train_kd.py validates
     between replays).  The eval forward after further replays equals the eval forward of a fresh module loaded with
-    the current state_dict, bit for bit."""
+    the current state_dict."""
     from kd6d.graph import GraphedKDStep
     from kd6d.kd_losses import PackedTargets
     from kd6d.libs.poses import ImageList
@@ -472,5 +476,77 @@ def test_eval_between_graph_replays_sees_current_weights(gpu_device):
     fresh.load_state_dict(student.state_dict())
     want = eval_logits(fresh)
     torch.cuda.synchronize()
-    assert not torch.equal(first[0], second[0]), "the replayed steps did not train"
-    assert torch.equal(second[0], want[0]) and torch.equal(second[1], want[1])
+    # (GroupNorm statistics are accumulated with float atomics: equal up to their summation order)
+    assert float((first[1] - second[1]).abs().max()) > 1e-2, "the replayed steps did not train"
+    torch.testing.assert_close(second[0], want[0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(second[1], want[1], rtol=1e-4, atol=1e-4)
+
+
+def test_data_parallel_step_semantics_two_shards(gpu_device):
+    """What N = 2 ranks compute (libs/train_libs.py:117,272): each rank runs the step on its shard of
+    the global batch (per-rank loss sums / KD mean, local BatchNorm statistics), the flat gradient buckets are
+    averaged, and every rank applies clip + AdamW with lr = BASE_LR / N.  Emulated on one GPU -- the HIP step on the
+    two half-batches one after the other, bucket mean, fused optimiser -- against the oracle doing the same."""
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import INTERNAL_K, MESH_DIAMETERS, make_batch
+    from oracle import kd_step_ref as O
+    dev = gpu_device
+    N, Bs, crop, arch = 2, 2, 128, "darknet_tiny_h"
+    bias = [1.0] + [-6.0] * 14
+    teacher = build("darknet53", "fp32", 2, dev, bias).eval()
+    student = build(arch, "fp32", 1, dev).train()
+    base_lr = 1e-3 / N
+    opt = FusedClipAdamW(student, lr=base_lr, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, base_lr, 10100, pct_start=0.05, cycle_momentum=False,
+                                                anneal_strategy="linear")
+    ref = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0, teacher_cls_bias=bias,
+                      n_gpu=N)
+    levels = [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
+    cells = sum(h * w for h, w in levels)
+    counts = [h * w for h, w in levels]
+    st = student.net.store
+    buckets, ref_buckets, losses, ref_losses = [], [], [], []
+    for r in range(N):                                   # seed = 1000 * rank + step, as bench.py / train_kd.py shard
+        images, targets = make_batch(Bs, 1000 * r, crop=crop)
+        keys_ref = torch.rand(Bs * cells, generator=torch.Generator().manual_seed(50 + r))
+        student._debug_keys = keys_ref[ref_to_packed_rows(Bs, levels)].to(dev)
+
+        def choose(vp, n, im, l, g, keys_ref=keys_ref):
+            off = im * cells + sum(counts[:l])
+            return torch.argsort(keys_ref[off + vp], stable=True)[:n]
+
+        out, _ = ref.forward_backward(images.tensors, [t.as_dict() for t in targets], choose=choose)
+        ref_buckets.append({k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None})
+        ref_losses.append([float(out[k]) for k in ("loss_cls", "loss_reg", "loss_kd")])
+        img, tgt = ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)
+        student.zero_grad()
+        with torch.no_grad():
+            pred_t = teacher(img, targets=tgt, is_teacher=True)
+        _, ld = student(img, targets=tgt, pred_t=pred_t)
+        (ld["loss_cls"] * 0.1 + ld["loss_reg"] * 1.0 + ld["loss_kd"] * 5.0).backward()
+        buckets.append(st.grads[:st.n_train].clone())
+        losses.append([float(ld[k]) for k in ("loss_cls", "loss_reg", "loss_kd")])
+    np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-3)
+    assert abs(losses[0][0] - losses[1][0]) > 1e-3 * abs(losses[0][0]), "the two shards must differ"
+    # the collective: mean of the rank buckets (kd6d_comm_allreduce(mean) / ReduceOp.AVG)
+    st.grads[:st.n_train].copy_((buckets[0] + buckets[1]) / N)
+    for k, p in ref.student.named_parameters():
+        if k in ref_buckets[0]:
+            p.grad = (ref_buckets[0][k] + ref_buckets[1][k]) / N
+    ref_mean = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
+    got_mean = {k: p.grad.detach().clone().cpu() for k, p in student.named_parameters() if p.grad is not None}
+    gn_ref = ref.optimizer_step()
+    opt.step(); sched.step()
+    torch.cuda.synchronize()
+    assert opt.param_groups[0]["lr"] == pytest.approx(ref.opt.param_groups[0]["lr"], rel=1e-12)
+    assert float(opt.grad_norm()) == pytest.approx(gn_ref, rel=5e-3)
+    for k, r in ref_mean.items():
+        tol = 2e-2 * float(r.abs().max()) + 1e-6 * gn_ref
+        assert float((got_mean[k] - r).abs().max()) <= tol, k
+    sd = student.state_dict()
+    for k, v in ref.student.state_dict().items():
+        if k.endswith("num_batches_tracked") or "running_" in k:
+            continue                                      # BN statistics are per rank: not part of the exchange
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=2e-3, atol=2e-4, msg=lambda m, k=k: "%s: %s" % (k, m))

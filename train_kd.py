@@ -26,7 +26,7 @@ import torch  # noqa: E402
 from kd6d.arguments.argument_kd import get_args  # noqa: E402
 from kd6d._lib import lib  # noqa: E402
 from kd6d.kd_losses import PackedTargets  # noqa: E402
-from kd6d.libs.distributed import get_rank, shard_batch, synchronize  # noqa: E402
+from kd6d.libs.distributed import get_rank, init_exchange, shard_batch, synchronize  # noqa: E402
 from kd6d.libs.eval_libs import valid  # noqa: E402
 from kd6d.libs.poses import ImageList  # noqa: E402
 from kd6d.libs.train_libs import build_model, build_model_teacher  # noqa: E402
@@ -80,6 +80,7 @@ if __name__ == "__main__":
     if cfg["RUNTIME"]["DISTRIBUTED"]:
         torch.distributed.init_process_group(backend="nccl", init_method="env://")
         synchronize()
+        print("gradient exchange: " + init_exchange())      # kd6d_comm_* over librccl (include/kd6d.h)
 
     if not cfg["RUNTIME"]["SYNTHETIC"]:
         raise SystemExit("the BOP/LINEMOD reader is outside the KD-step hot path (SURVEY.md 8(f)-4); "
