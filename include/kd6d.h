@@ -225,12 +225,13 @@ int kd6d_image_to_nhwc(int dtype, const float* img_nchw, void* out, int B, int C
  * and its autograd.  Image b uses student points xs[(s_start[b]+i)*8+k][2] (i < s_cnt[b]) with
  * weights alpha[(..)*8+k] and teacher points/weights likewise; reach <= 0 means balanced.
  * Outputs: loss_img[b] = sum_k S_k (0 when a set is empty: valid_img[b] = 0; -1 = set larger than
- * kd6d_sinkhorn_max_points()), grad_xs / grad_alpha = d loss_img / d xs, alpha. */
+ * kd6d_sinkhorn_max_points()), loss_kp (optional, n_images*8) = the eight S_k themselves (what SamplesLoss returns
+ * for a batch of 8 problems), grad_xs / grad_alpha = d loss_img / d xs, alpha. */
 int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, const int32_t* s_start,
                               const int32_t* s_cnt, const float* yt, const float* beta,
                               const int32_t* t_start, const int32_t* t_cnt, int n_images, float p, float blur,
-                              float scaling, float reach, float* loss_img, int32_t* valid_img, float* grad_xs,
-                              float* grad_alpha, void* stream);
+                              float scaling, float reach, float* loss_img, int32_t* valid_img, float* loss_kp,
+                              float* grad_xs, float* grad_alpha, void* stream);
 int kd6d_sinkhorn_max_points(void);
 
 /* ---- loss-side kernels (cls logits (rows,16) fp32 [15 classes + pad], reg logits (rows,240)) --

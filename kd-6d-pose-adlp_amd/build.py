@@ -24,27 +24,48 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _digest():
+def _headers_digest():
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)) + ["../../include/kd6d.h"]:
-        path = os.path.join(CSRC, name)
-        if name.endswith((".hip", ".h")) and os.path.isfile(path):
-            with open(path, "rb") as f:
-                h.update(name.encode())
-                h.update(f.read())
+    for path in sorted([os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith(".h")]
+                       + [os.path.join(HERE, "..", "include", "kd6d.h")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode())
+            h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    return h
+
+
+def _source_digest(src, base):
+    h = base.copy()
+    with open(os.path.join(CSRC, src), "rb") as f:
+        h.update(f.read())
     return h.hexdigest()
 
 
 def build(force=False, verbose=True):
-    stamp = os.path.join(CSRC, ".build_stamp")
-    dig = _digest()
-    if not force and os.path.exists(OUT) and os.path.exists(stamp):
-        with open(stamp) as f:
-            if f.read().strip() == dig:
-                return OUT
+    """Compile every csrc/*.hip whose source, the shared headers or the flags changed since its object was built
+    (one stamp per object), then link.  Returns the path of the shared object."""
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    base = _headers_digest()
+    srcs = _sources()
+    digests = {src: _source_digest(src, base) for src in srcs}
+
+    def stale(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        stamp = obj + ".stamp"
+        if force or not os.path.exists(obj) or not os.path.exists(stamp):
+            return True
+        with open(stamp) as f:
+            return f.read().strip() != digests[src]
+
+    todo = [s for s in srcs if stale(s)]
+    link_stamp = os.path.join(CSRC, ".build_stamp")
+    all_dig = hashlib.sha256("".join(digests[s] for s in srcs).encode()).hexdigest()
+    if not todo and os.path.exists(OUT) and os.path.exists(link_stamp):
+        with open(link_stamp) as f:
+            if f.read().strip() == all_dig:
+                return OUT
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -54,16 +75,19 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
+        with open(obj + ".stamp", "w") as f:
+            f.write(digests[src])
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
-        objs = list(ex.map(compile_one, _sources()))
+        list(ex.map(compile_one, todo))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    with open(stamp, "w") as f:
-        f.write(dig)
+    with open(link_stamp, "w") as f:
+        f.write(all_dig)
     return OUT
 
 

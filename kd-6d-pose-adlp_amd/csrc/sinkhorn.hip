@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
     const int* __restrict__ s_cnt, const float* __restrict__ yt, const float* __restrict__ beta,
     const int* __restrict__ t_start, const int* __restrict__ t_cnt,
     float blur, float scaling, float reach, float* __restrict__ loss_img, int* __restrict__ valid_img,
-    float* __restrict__ gx_out, float* __restrict__ galpha_out, int slow_path) {
+    float* __restrict__ loss_kp, float* __restrict__ gx_out, float* __restrict__ galpha_out, int slow_path) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   WaveLds* all = reinterpret_cast<WaveLds*>(smem_raw);
   float* red = reinterpret_cast<float*>(smem_raw + sizeof(WaveLds) * kWaves);  // [kWaves][5]
@@ -93,10 +93,12 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
   const int t0 = t_start[b], M = t_cnt[b];
   if (N <= 0 || M <= 0) {          // reference: image skipped (loss_libs.py:25-28)
     if (threadIdx.x == 0) { loss_img[b] = 0.f; valid_img[b] = 0; }
+    if (loss_kp && threadIdx.x < kWaves) loss_kp[b * kWaves + threadIdx.x] = 0.f;
     return;
   }
   if (N > kCap || M > kCap) {      // caller must route larger sets to the dense kernel
     if (threadIdx.x == 0) { loss_img[b] = 0.f; valid_img[b] = -1; }
+    if (loss_kp && threadIdx.x < kWaves) loss_kp[b * kWaves + threadIdx.x] = 0.f;
     return;
   }
   WaveLds& L = all[wave];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
       else part = w * (a_y - b_y);
     }
     part = wave_sum(part);
-    if (lane == 0) red[wave * 5 + 4] = part;
+    if (lane == 0) { red[wave * 5 + 4] = part; if (loss_kp) loss_kp[b * kWaves + wave] = part; }
     __syncthreads();
     if (threadIdx.x == 0) {
       float tot = 0.f;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
     else part += w * (a_y - b_y);
   }
   part = wave_sum(part);
-  if (lane == 0) red[wave * 5 + 4] = part;
+  if (lane == 0) { red[wave * 5 + 4] = part; if (loss_kp) loss_kp[b * kWaves + wave] = part; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot = 0.f;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(64 * kWaves) void sinkhorn_small_kernel(
 extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, const int32_t* s_start,
                                          const int32_t* s_cnt, const float* yt, const float* beta,
                                          const int32_t* t_start, const int32_t* t_cnt, int n_images, float p, float blur, float scaling,
-                                         float reach, float* loss_img, int32_t* valid_img,
+                                         float reach, float* loss_img, int32_t* valid_img, float* loss_kp,
                                          float* grad_xs, float* grad_alpha, void* stream) {
   KD6D_CHECK_ARG(xs && alpha && s_start && s_cnt && yt && beta && t_start && t_cnt && loss_img && valid_img && grad_xs &&
                      grad_alpha,
@@ -400,8 +402,8 @@ extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, co
   const char* lanes_env = getenv("KD6D_SINKHORN_LANES");
   const int slow = lanes_env && lanes_env[0] == '0';
   hipLaunchKernelGGL(sinkhorn_small_kernel, dim3(n_images), dim3(64 * kWaves), lds, st, xs, alpha,
-                     s_start, s_cnt, yt, beta, t_start, t_cnt, blur, scaling, reach, loss_img, valid_img, grad_xs,
-                     grad_alpha, slow);
+                     s_start, s_cnt, yt, beta, t_start, t_cnt, blur, scaling, reach, loss_img, valid_img, loss_kp,
+                     grad_xs, grad_alpha, slow);
   KD6D_CHECK_LAUNCH("kd6d_sinkhorn_div_fwd_bwd");
   return KD6D_OK;
 }

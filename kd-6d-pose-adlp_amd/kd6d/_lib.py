@@ -77,7 +77,7 @@ SIGNATURES = {
     "kd6d_sumpool2": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
     "kd6d_eltwise": [_I, _I, _P, _P, _P, _I64, _P],
     "kd6d_image_to_nhwc": [_I, _P, _P, _I, _I, _I, _I, _I, _P],
-    "kd6d_sinkhorn_div_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P],
+    "kd6d_sinkhorn_div_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     "kd6d_sinkhorn_max_points": [],
     "kd6d_sinkhorn_dense_workspace_floats": [_I, _I, _I],
     "kd6d_sinkhorn_dense_diameter": [_P, _P, _I, _I, _I, _P, _P, _P],

@@ -2,10 +2,11 @@
 
 Every reference flag keeps its name, type and default.  Additive flags of this build:
 --precision {bf16,fp32}, --synthetic, --skip_teacher_eval, --batch_size (per-step GLOBAL batch,
-overrides SOLVER.IMS_PER_BATCH), --image_size.
+overrides SOLVER.IMS_PER_BATCH), --image_size, --mixed_classes; yaml files may name a `_BASE_` file.
 """
 import argparse
 import copy
+import os
 
 import yaml
 
@@ -62,7 +63,29 @@ def get_argparser():
     p.add_argument("--batch_size", type=int, default=0, help="global batch; 0 = SOLVER.IMS_PER_BATCH")
     p.add_argument("--image_size", type=int, default=256, help="synthetic crop size")
     p.add_argument("--val_freq", type=int, default=0, help="validate every N steps; 0 = the backbone's default")
+    p.add_argument("--mixed_classes", type=str2bool, nargs="?", const=True, default=None,
+                   help="synthetic batches mix the 13 LINEMOD classes (default: DATASETS.MIXED_CLASSES of the yaml)")
     return p
+
+
+def load_yaml(path):
+    """yaml -> dict.  A top-level `_BASE_: other.yaml` (path relative to the file; additive key of this build) is
+    loaded first and the file's own sections are merged over it key by key."""
+    with open(path, "r") as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader) or {}
+    base = cfg.pop("_BASE_", None)
+    if base is None:
+        return cfg
+    out = load_yaml(os.path.join(os.path.dirname(os.path.abspath(path)), base))
+
+    def merge(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                merge(dst[k], v)
+            else:
+                dst[k] = v
+    merge(out, cfg)
+    return out
 
 
 def _runtime(args, config_file, weight_file):
@@ -71,14 +94,16 @@ def _runtime(args, config_file, weight_file):
 
 
 def build_cfgs(args):
-    with open(args.config_file, "r") as f:
-        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    cfg = load_yaml(args.config_file)
     cfg["RUNTIME"] = _runtime(args, args.config_file, args.weight_file)
     cfg["RUNTIME"]["WORKING_DIR"] = args.working_dir
     cfg["RUNTIME"]["SYNTHETIC"] = bool(args.synthetic)
     cfg["RUNTIME"]["SKIP_TEACHER_EVAL"] = bool(args.skip_teacher_eval)
     cfg["RUNTIME"]["LAUNCH"] = args.launch
     cfg["RUNTIME"]["IMAGE_SIZE"] = int(args.image_size)
+    if args.mixed_classes is not None:
+        cfg["DATASETS"]["MIXED_CLASSES"] = bool(args.mixed_classes)
+    cfg["DATASETS"].setdefault("MIXED_CLASSES", False)
     if len(args.test_file) > 0:
         cfg["DATASETS"]["TEST"] = args.test_file
     cfg["MODEL"]["BACKBONE"] = args.backbone
@@ -95,8 +120,7 @@ def build_cfgs(args):
     if cfg["KD"]["LEVEL"] == "pred":
         cfg["KD"].update(GLEVEL=args.glevel, GTYPE=args.gtype, GP=args.p, GBLUR=args.blur, GnD=args.gnD,
                          WEIGHTED_OT=args.weightedOT, DETACH=args.wot_detach, SCALING=args.scaling, REACH=args.reach)
-    with open(args.config_file_t, "r") as f:
-        cfg_t = yaml.load(f, Loader=yaml.FullLoader)
+    cfg_t = load_yaml(args.config_file_t)
     cfg_t["RUNTIME"] = _runtime(args, args.config_file_t, args.weight_file_t)
     cfg_t["MODEL"]["BACKBONE"] = args.backbone_t
     cfg_t = custom_cfg(cfg_t)

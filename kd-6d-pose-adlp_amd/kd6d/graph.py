@@ -178,7 +178,7 @@ class GraphedKDStep:
 
     def _capture(self):
         self.student._defer_allreduce = True
-        if self.pipeline and type(self) is GraphedKDStep and self._blocks is None:
+        if self.pipeline and self._blocks is None:
             self._make_blocks()
         snap = self._snapshot()                              # the warm-up steps below must not train
         side = torch.cuda.Stream()
@@ -253,137 +253,3 @@ class GraphedKDStep:
             self._capture()
         self.pending = False
         return self._replay()      # the teacher re-reads the same (last) batch: harmless, results unused
-
-
-class GroupedKDStep(GraphedKDStep):
-    """`GraphedKDStep(pipeline=True)` with teacher look-ahead over GROUPS of batches.
-
-    At B = 16 most of the frozen teacher's layers are tail-bound (stage 4/5 and the FPN top have 64-256 output
-    tiles for 256 CUs): one forward over 4 batches costs 2.5x one over a single batch (measured, conv time
-    1.62 -> 4.05 ms), its GroupNorm / selection launches and kernel boundaries amortise 4x as well.  So the
-    teacher runs ONCE per group of G incoming batches on G*B images, on its own stream, and the student then
-    trains on those G batches one by one with the teacher cells sliced out of the group's result.  Every image
-    still gets exactly one teacher forward and every batch one student step with batch size B; eval-mode
-    BatchNorm and per-sample GroupNorm make the teacher's output independent of how images are grouped.
-    Call k returns the losses of batch k - G (None while the first group fills); `flush()` drains.
-    """
-
-    def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3,
-                 concurrent=True, group=4):
-        super().__init__(teacher, student, optimizer, loss_weights, cfg_kd, warmup, concurrent, pipeline=True)
-        self.G = int(group)
-        self.k = 0                    # batches received
-        self.trained = 0              # batches trained
-        self.slots = None             # [2][G] static (images, targets) of the incoming / current group
-        self.inc = 0                  # which slot set is being filled
-        self.t_images = self.t_tgt = None      # teacher graph inputs: G*B images, G*B bbox_trans
-        self.g_teacher = None
-        self.have_cur = False
-
-    # ---- teacher side -------------------------------------------------------------------------
-    def _teacher_group(self):
-        with torch.no_grad():
-            return self.teacher(self.t_images, targets=self.t_tgt, is_teacher=True, cfg_kd=self.cfg_kd)
-
-    def _launch_teacher(self, n_valid):
-        """Group complete: hand its images to the teacher stream and run the teacher once on all of them."""
-        main, T = torch.cuda.current_stream(), self.teacher_stream
-        T.wait_stream(main)                      # the student is done with the previous group's cells / inputs
-        with torch.cuda.stream(T):
-            B = self.slots[self.inc][0][0].tensors.shape[0]
-            for j in range(self.G):
-                img, tgt = self.slots[self.inc][j]
-                self.t_images.tensors[j * B:(j + 1) * B].copy_(img.tensors, non_blocking=True)
-                self.t_tgt.bbox_trans[j * B:(j + 1) * B].copy_(tgt.bbox_trans, non_blocking=True)
-            if self.g_teacher is None:
-                for _ in range(2):
-                    self.t_out = self._teacher_group()
-                torch.cuda.synchronize()
-                self.g_teacher = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_teacher, capture_error_mode="thread_local"):
-                    self.t_out = self._teacher_group()
-            self.g_teacher.replay()
-        self.inc ^= 1
-        self.have_cur = True
-        self.cur_valid = n_valid
-
-    # ---- student side ---------------------------------------------------------------------------
-    def _forward_backward(self):                 # what G1 captures here: the student step only
-        self.student.zero_grad()
-        return self._student_step(self.t_cur)
-
-    def _train_slot(self, j):
-        main = torch.cuda.current_stream()
-        if j == 0:
-            main.wait_stream(self.teacher_stream)          # the group's teacher cells are complete
-        img, tgt = self.slots[self.inc ^ 1][j]
-        self.images.tensors.copy_(img.tensors, non_blocking=True)
-        self.tgt.copy_from(tgt)
-        if self.t_cur is None:
-            self.t_cur = self.t_out.slice_static(j, self.G)
-        self.t_cur.copy_slice_from(self.t_out, j, self.G)
-        if self.g_step is None:
-            self._capture()
-        self.trained += 1
-        return self._replay()
-
-    # ---- public ---------------------------------------------------------------------------------
-    def __call__(self, images, tgt):
-        if not isinstance(tgt, PackedTargets):
-            tgt = PackedTargets(tgt, self.student.net.device)
-        x = images.tensors if hasattr(images, "tensors") else images
-        if self.slots is None:
-            sizes = getattr(images, "sizes", None)
-            self.slots = [[(ImageList(torch.empty_like(x), sizes), tgt.clone_static()) for _ in range(self.G)]
-                          for _ in range(2)]
-            self.images = ImageList(torch.empty_like(x), sizes)
-            self.tgt = tgt.clone_static()
-            B = x.shape[0]
-            self.t_images = ImageList(x.new_empty((self.G * B,) + tuple(x.shape[1:])), None)
-            self.t_tgt = PackedTargets.teacher_view(tgt, self.G)
-        j = self.k % self.G
-        out = None
-        if j == self.G - 1:
-            # last batch of the incoming group: start its teacher first, beside the current group's last student step
-            img_s, tgt_s = self.slots[self.inc][j]
-            img_s.tensors.copy_(x, non_blocking=True)
-            tgt_s.copy_from(tgt)
-            had_cur, cur_set = self.have_cur, self.inc ^ 1
-            if had_cur:
-                # the student still needs slot j of the CURRENT group and its cells: copy them out before the
-                # teacher stream may overwrite t_out
-                out = self._train_slot(j)
-            self._launch_teacher(self.G)
-        else:
-            img_s, tgt_s = self.slots[self.inc][j]
-            img_s.tensors.copy_(x, non_blocking=True)
-            tgt_s.copy_from(tgt)
-            if self.have_cur:
-                out = self._train_slot(j)
-        self.k += 1
-        return out
-
-    def flush(self, on_step=None):
-        """Train on everything still buffered: the complete current group's remaining slots, then the (possibly
-        partial) incoming group.  on_step(losses) is called after every drained step (the loss tensors are
-        static: read them, advance the lr scheduler, ... there)."""
-        class _Outs(list):
-            def append(self_, v):
-                list.append(self_, v)
-                if on_step is not None:
-                    on_step(v)
-        outs = _Outs()
-        j0 = self.k % self.G
-        if self.have_cur:
-            for j in range(j0, self.G if j0 else 0):
-                outs.append(self._train_slot(j))
-        if j0:                                   # partial incoming group: the teacher runs on the whole static
-            self._launch_teacher(j0)             # buffer (stale slots are ignored), the student on the valid ones
-            for j in range(j0):
-                outs.append(self._train_slot(j))
-            self.k += self.G - j0
-        elif self.trained < self.k:              # a complete group whose teacher ran but was never trained
-            for j in range(self.G):
-                outs.append(self._train_slot(j))
-        self.have_cur = False
-        return outs[-1] if outs else None

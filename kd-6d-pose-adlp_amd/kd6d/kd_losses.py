@@ -113,16 +113,43 @@ class PackedTargets:
         self.mask, self.flat_f, self.flat_i = mask, flat_f, flat_i
         self._rebind()
 
+
+class TeacherKnowledge(dict):
+    """pred_t of the reference (models/model_kd.py:83-92).  The device-side slot arrays are what the
+    student step consumes; the reference-named entries are materialised (with a sync) on demand."""
+
+    def __init__(self, t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta, cap, batch, flats=None):
+        super().__init__()
+        self.t_cnt, self.t_kp, self.t_score, self.t_row = t_cnt, t_kp, t_score, t_row
+        self.t_kp_norm, self.t_beta = t_kp_norm, t_beta
+        self.cap, self.batch = cap, batch
+        self.t_start = torch.arange(batch, dtype=torch.int32, device=t_cnt.device) * cap
+        self.flats = flats            # (fp32, int32) buffers all the slot arrays are views of
+
     @staticmethod
-    def teacher_view(tgt, groups):
-        """What the teacher's forward reads of the targets (the crop affines, postprocess_kd.py:171-179) for
-        `groups` batches back to back."""
-        out = object.__new__(PackedTargets)
-        out.batch = tgt.batch * groups
-        out.bbox_trans = tgt.bbox_trans.new_zeros((out.batch, 2, 3))
-        out.frame_wh = tgt.frame_wh
-        out.mask_h, out.mask_w = tgt.mask_h, tgt.mask_w
-        return out
+    def from_flats(wf, wi, batch, cap):
+        """Slot arrays as views of one fp32 (n*48) and one int32 (n + batch rounded up to 4) buffer."""
+        n, b = batch * cap, batch
+        return TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
+                                wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), cap, b, (wf, wi))
+
+    def clone_static(self):
+        """Persistent copy (own storage) that `copy_from` refreshes: the double buffer of the step pipeline."""
+        wf, wi = (t.clone() for t in self.flats)
+        return TeacherKnowledge.from_flats(wf, wi, self.batch, self.cap)
+
+    def copy_from(self, other):
+        self.mask.copy_(other.mask, non_blocking=True)
+        self.flat_f.copy_(other.flat_f, non_blocking=True)
+        self.flat_i.copy_(other.flat_i, non_blocking=True)
+
+    def rebind_storage(self, mask, flat_f, flat_i):
+        """Move the three device buffers into caller-owned storage of the same shapes (contents are copied)."""
+        for new, old in ((mask, self.mask), (flat_f, self.flat_f), (flat_i, self.flat_i)):
+            assert new.shape == old.shape and new.dtype == old.dtype
+            new.copy_(old)
+        self.mask, self.flat_f, self.flat_i = mask, flat_f, flat_i
+        self._rebind()
 
 
 class TeacherKnowledge(dict):
@@ -253,6 +280,7 @@ class KDLoss:
             raise NotImplementedError("unweighted OT (--weightedOT false) is not implemented on the HIP path")
         self.cap = cap
         self.ctx = None
+        self.anchor_sizes, self.anchor_strides = ANCHOR_SIZES, ANCHOR_STRIDES      # configs/ape.yaml:3-4
 
     def assign(self, levels, batch, tgt, keys=None):
         """SSC target assignment + the zeroed per-step workspaces.  Depends on the targets only, not on the student's
@@ -260,7 +288,7 @@ class KDLoss:
         dev = tgt.mask.device
         rows = batch * sum(h * w for h, w in levels)
         cap = self.cap
-        lv = make_levels(batch, levels)
+        lv = make_levels(batch, levels, self.anchor_sizes, self.anchor_strides)
         if keys is None:
             keys = torch.rand(rows, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -284,7 +312,7 @@ class KDLoss:
         dev = cls_s.device
         rows = cls_s.shape[0]
         cap = self.cap
-        lv = make_levels(batch, levels)
+        lv = make_levels(batch, levels, self.anchor_sizes, self.anchor_strides)
         if self.diameters is None or self.diameters.device != dev:
             self.diameters = torch.tensor(self.diameters_host, dtype=torch.float32, device=dev)
         if pre is None or pre["rows"] != rows or pre["levels"] != tuple(levels) or pre["batch"] != batch:
@@ -312,7 +340,7 @@ class KDLoss:
         if teacher is not None:
             check(lib.kd6d_sinkhorn_div_fwd_bwd(P(xs), P(alpha), P(s_start), P(pos_cnt), P(teacher.t_kp_norm),
                                                 P(teacher.t_beta), P(teacher.t_start), P(teacher.t_cnt), batch, self.p,
-                                                self.blur, self.scaling, self.reach, P(loss_img), P(valid),
+                                                self.blur, self.scaling, self.reach, P(loss_img), P(valid), None,
                                                 P(g_xs), P(g_alpha), st), "kd6d_sinkhorn_div_fwd_bwd")
             check(lib.kd6d_kd_mean(P(loss_img), P(valid), batch, P(losses[2:3]), P(n_valid), st), "kd6d_kd_mean")
         self.ctx = dict(lv=lv, cls=cls_s, reg=reg_s, labels=labels, pos_cnt=pos_cnt, pos_row=pos_row, pos_gt=pos_gt,

@@ -359,10 +359,11 @@ def image_to_nhwc(img, dtype, cpad=8, out=None):
     return out
 
 
-def sinkhorn_div(xs, alpha, s_start, s_cnt, yt, beta, t_start, t_cnt, n_images, p, blur, scaling, reach):
+def sinkhorn_div(xs, alpha, s_start, s_cnt, yt, beta, t_start, t_cnt, n_images, p, blur, scaling, reach, loss_kp=None):
     """xs (P,8,2), alpha (P,8), yt (M,8,2), beta (M,8); image b owns student rows
     [s_start[b], s_start[b]+s_cnt[b]) and teacher rows likewise (int32 device arrays).
-    Returns loss_img (B), valid_img (B) int32, grad_xs (P,8,2), grad_alpha (P,8)."""
+    Returns loss_img (B), valid_img (B) int32, grad_xs (P,8,2), grad_alpha (P,8); loss_kp: optional (B,8) fp32
+    output of the eight per-keypoint divergences."""
     dev = xs.device
     loss = torch.empty(n_images, dtype=torch.float32, device=dev)
     valid = torch.empty(n_images, dtype=torch.int32, device=dev)
@@ -370,7 +371,7 @@ def sinkhorn_div(xs, alpha, s_start, s_cnt, yt, beta, t_start, t_cnt, n_images, 
     ga = torch.zeros_like(alpha)
     check(lib.kd6d_sinkhorn_div_fwd_bwd(_ptr(xs), _ptr(alpha), _ptr(s_start), _ptr(s_cnt), _ptr(yt), _ptr(beta),
                                         _ptr(t_start), _ptr(t_cnt), n_images, p, blur, scaling,
-                                        reach if reach is not None else -1.0, _ptr(loss), _ptr(valid),
+                                        reach if reach is not None else -1.0, _ptr(loss), _ptr(valid), _ptr(loss_kp),
                                         _ptr(gx), _ptr(ga), _stream()), "kd6d_sinkhorn_div_fwd_bwd")
     return loss, valid, gx, ga
 

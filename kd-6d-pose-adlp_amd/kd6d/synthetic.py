@@ -24,8 +24,9 @@ def cube_keypoints(diameters=MESH_DIAMETERS):
     return signs[None] * e[:, None, None]
 
 
-def make_batch(batch, seed, crop=256, mixed_classes=False, full_frame=False, class_id=0):
-    """Returns (ImageList on CPU, list[PoseAnnot] on CPU)."""
+def make_batch(batch, seed, crop=256, mixed_classes=False, full_frame=False, class_id=0, class_offset=0):
+    """Returns (ImageList on CPU, list[PoseAnnot] on CPU).  mixed_classes: image i shows LINEMOD class
+    (class_offset + i) mod 13 (a rank passes its first global image index as class_offset)."""
     rng = np.random.default_rng(seed)
     K = np.asarray(INTERNAL_K, np.float32).reshape(3, 3)
     kp3d = cube_keypoints()
@@ -33,7 +34,7 @@ def make_batch(batch, seed, crop=256, mixed_classes=False, full_frame=False, cla
     imgs = rng.standard_normal((batch, 3, H, W), dtype=np.float32)
     targets = []
     for i in range(batch):
-        c = LINEMOD_CLASSES[i % len(LINEMOD_CLASSES)] if mixed_classes else class_id
+        c = LINEMOD_CLASSES[(class_offset + i) % len(LINEMOD_CLASSES)] if mixed_classes else class_id
         q, r = np.linalg.qr(rng.standard_normal((3, 3)))
         q = q * np.sign(np.diag(r))[None, :]
         if np.linalg.det(q) < 0:

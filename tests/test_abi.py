@@ -39,7 +39,7 @@ def test_argument_checks_fail_loudly_without_gpu():
     g.seg[0].out_h = 5
     rc = lib.kd6d_conv2d_dgrad(ctypes.byref(g), _lib.KD6D_F32, None, None, None, 0, None)
     assert rc == -1 and b"inconsistent" in lib.kd6d_last_error()
-    rc = lib.kd6d_sinkhorn_div_fwd_bwd(*([None] * 8), 4, 1.0, 0.001, 0.5, 0.5, *([None] * 5))
+    rc = lib.kd6d_sinkhorn_div_fwd_bwd(*([None] * 8), 4, 1.0, 0.001, 0.5, 0.5, *([None] * 6))
     assert rc == -1
     try:
         _lib.check(rc, "kd6d_sinkhorn_div_fwd_bwd")

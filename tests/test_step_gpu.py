@@ -370,77 +370,6 @@ def test_graph_replay_matches_eager_steps(gpu_device, precision):
     assert abs(np.abs(p_p - p0).mean() / d_e.mean() - 1.0) < 0.02
 
 
-def test_grouped_teacher_matches_eager_steps(gpu_device):
-    """GroupedKDStep: the frozen teacher runs once per group of G = 2 incoming batches (2*B images in one
-    forward), the student steps on the single batches with the cells sliced out of the group result.  Same
-    training sequence as the eager loop: identical first step, same schedule afterwards; a trailing partial
-    group is drained by flush()."""
-    from kd6d.graph import GroupedKDStep
-    from kd6d.kd_losses import PackedTargets
-    from kd6d.libs.poses import ImageList
-    from kd6d.optim import FusedClipAdamW
-    from kd6d.synthetic import make_batch
-    dev = gpu_device
-    precision = "fp32"
-    B, crop, arch = 2, 64, "darknet_tiny_h"
-    bias = [1.0] + [-6.0] * 14
-    teacher = build("darknet53", precision, 2, dev, bias).eval()
-    batches = []
-    for i in range(3):
-        images, targets = make_batch(B, 10 + i, crop=crop)
-        batches.append((ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)))
-    rows = B * sum((crop // 8 // 2 ** i) ** 2 for i in range(4))
-    keys = torch.rand(rows, generator=torch.Generator().manual_seed(3)).to(dev)
-    order = [0, 1, 2, 0, 1]                      # 5 batches: two full groups and a partial one
-
-    def make():
-        student = build(arch, precision, 1, dev).train()
-        student._debug_keys = keys
-        opt = FusedClipAdamW(student, lr=1e-3)
-        sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 40, pct_start=0.25, cycle_momentum=False,
-                                                    anneal_strategy="linear")
-        return student, opt, sched
-
-    # eager reference
-    student, opt, sched = make()
-    h_e = []
-    for b in order:
-        img, tgt = batches[b]
-        student.zero_grad()
-        with torch.no_grad():
-            pred_t = teacher(img, targets=tgt, is_teacher=True)
-        _, ld = student(img, targets=tgt, pred_t=pred_t)
-        (ld["loss_cls"] * 0.1 + ld["loss_reg"] + ld["loss_kd"] * 5.0).backward()
-        opt.step(); sched.step()
-        h_e.append([float(ld[k]) for k in ("loss_cls", "loss_reg", "loss_kd")] + [float(opt.grad_norm())])
-    torch.cuda.synchronize()
-    p_e = student.net.store.params.cpu().numpy().copy()
-    # grouped
-    student, opt, sched = make()
-    p0 = student.net.store.params.cpu().numpy().copy()
-    gs = GroupedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=2)
-    h_g = []
-
-    def on_step(ld):
-        sched.step()
-        h_g.append([float(ld[k]) for k in ("loss_cls", "loss_reg", "loss_kd")] + [float(opt.grad_norm())])
-
-    for i, b in enumerate(order):
-        ld = gs(*batches[b])
-        assert (ld is None) == (i < 2)           # the first group only fills
-        if ld is not None:
-            on_step(ld)
-    gs.flush(on_step)
-    torch.cuda.synchronize()
-    p_g = student.net.store.params.cpu().numpy().copy()
-    h_e, h_g = np.array(h_e), np.array(h_g)
-    assert h_g.shape == h_e.shape == (5, 4) and opt.steps == 5
-    assert (np.abs(h_g[0] - h_e[0]) <= np.abs(h_e[0]) * np.array([1e-3, 1e-3, 1e-3, 5e-3])).all(), (h_g[0], h_e[0])
-    np.testing.assert_allclose(h_g[1:, :3], h_e[1:, :3], rtol=0.1)
-    d_e, d_g = np.abs(p_e - p0), np.abs(p_g - p0)
-    assert abs(d_g.mean() / d_e.mean() - 1.0) < 0.02
-
-
 def test_eval_between_graph_replays_sees_current_weights(gpu_device):
     """A replayed optimiser graph changes the weights without passing through Python: the eval-mode BatchNorm
     scale/shift cached by the previous validation must not survive it (every VAL_FREQ steps train_kd.py validates

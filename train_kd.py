@@ -39,7 +39,9 @@ def synthetic_loader(cfg, device, n_batches=8):
     size = cfg["RUNTIME"].get("IMAGE_SIZE", 256)
     batches = []
     for i in range(n_batches):
-        images, targets = make_batch(per_gpu, 1000 * get_rank() + i, crop=size)
+        images, targets = make_batch(per_gpu, 1000 * get_rank() + i, crop=size,
+                                     mixed_classes=cfg["DATASETS"].get("MIXED_CLASSES", False),
+                                     class_offset=get_rank() * per_gpu)
         batches.append((images.to(device), PackedTargets(targets, device), None))
     while True:
         for b in batches:
@@ -52,7 +54,8 @@ def synthetic_valid_loader(cfg, device, n_batches=2):
     size = cfg["RUNTIME"].get("IMAGE_SIZE", 256)
     loader, meshes = [], None
     for i in range(n_batches):
-        images, targets = make_batch(per_gpu, 900000 + i, crop=size)
+        images, targets = make_batch(per_gpu, 900000 + i, crop=size,
+                                     mixed_classes=cfg["DATASETS"].get("MIXED_CLASSES", False))
         metas = [{"path": "val%d_%d" % (i, j), "K": t.K.numpy(), "class_ids": [int(c) for c in t.class_ids],
                   "rotations": [r.numpy() for r in t.rotations],
                   "translations": [x.numpy().reshape(3, 1) for x in t.translations]} for j, t in enumerate(targets)]
