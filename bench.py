@@ -83,14 +83,32 @@ def make_cfg(arch, precision, workload="ape"):
 TEACHER_CLS_BIAS = [1.0] + [-6.0] * 14
 
 
+class _StdoutToStderr:
+    """The contract is ONE JSON line on stdout; librccl prints a version banner there when a communicator is created
+    (torch's and ours alike).  File descriptor 1 points at stderr until the JSON line is written."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        print(line, flush=True)
+
+
 def main():
     args = parse()
+    out_fd = _StdoutToStderr()
     if args.workload == "dense16d":
-        return bench_dense(args)
-    cfg_w = make_cfg("darknet_tiny_h", args.precision, args.workload)
+        return bench_dense(args, out_fd)
+    from kd6d.arguments.argument_kd import load_yaml
+    cfg_w = load_yaml(os.path.join(HERE, "configs", WORKLOAD_YAML[args.workload]))
     mixed = bool(cfg_w["DATASETS"].get("MIXED_CLASSES", False))
     if not args.student:
-        args.student = cfg_w["MODEL"]["BACKBONE"] if args.workload != "ape" else "darknet_tiny_h"
+        args.student = cfg_w["MODEL"]["BACKBONE"]
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -300,12 +318,12 @@ def main():
     barrier_timeouts = max(barrier_timeouts, int(ops.lib.kd6d_barrier_timeouts()))
     if rank == 0:
         out["barrier_timeouts"] = barrier_timeouts
-        print(json.dumps(out))
+        out_fd.emit(json.dumps(out))
     if barrier_timeouts != 0 or not finite:
         raise SystemExit("bench.py: INVALID run (barrier_timeouts=%d, finite=%s)" % (barrier_timeouts, finite))
 
 
-def bench_dense(args):
+def bench_dense(args, out_fd):
     """BASELINE config 5 (configs/dense16d.yaml): the OT distribution-alignment loss on a dense grid of local
     predictions, one problem per image -- loss value + d/dx + d/dalpha per step, N = M = GRID_H * GRID_W points of
     CODE_DIM dimensions.  One rank per GPU runs its own images (no collective: the problems are independent)."""
@@ -366,7 +384,7 @@ def bench_dense(args):
     if rank != 0:
         return
     head = results[0]
-    print(json.dumps({
+    out_fd.emit(json.dumps({
         "metric": "dense-OT KD loss images/sec (Sinkhorn divergence value + gradients, one 128x128x16-D problem per image)",
         "value": head["images_per_s"], "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 3),
         "ms_per_step": head["ms_per_image"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
