@@ -112,6 +112,26 @@ int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x,
 /* wt[cin][ky][kx][cout] <- w[cout][ky][kx][cin] for n_layers layers in one
  * launch.  desc_dev: int32[n_layers*6] = {w_off, wt_off, cout, cin, ksize,
  * first_block}; offsets in elements of the w / wt base arrays. */
+/* Grouped weight gradient (bf16): the dW (+ bias gradients) of several layers as ONE launch pair -- a work list of
+ * (layer, 128- or 16-channel row block of dW, kernel row ky, 128 input channels, pixel range) items sized so that
+ * `n_workgroups` workgroups run equally long, each leaving an fp32 partial tile in `slab`, and a reduction launch
+ * that adds the partial tiles into dw / dbias (+=, plain stores: bitwise reproducible).  Takes layers with
+ * stride 1, 1x1 or 3x3 "same" padding, cin %% 128 == 0 (kd6d_wgrad_group_supported); anything else stays on
+ * kd6d_conv2d_wgrad.  kd6d_wgrad_group_plan builds the work list in HOST memory (plan_host = NULL: size query);
+ * the caller copies it to the device once and replays kd6d_wgrad_group_launch with it (the plan holds the items'
+ * device pointers).  info[0] = workgroups, info[1] = reduction blocks, info[2] + (info[3] << 31) = slab floats. */
+typedef struct kd6d_wgrad_item {
+  kd6d_conv_geom geom;
+  const void* x;      /* input activations (rows_in, cin), bf16 */
+  const void* dy;     /* output gradient (rows_out, cout), bf16 */
+  float* dw;          /* (cout, k, k, cin) fp32, accumulated into */
+  float* dbias;       /* (cout) fp32 or NULL */
+} kd6d_wgrad_item;
+int kd6d_wgrad_group_supported(const kd6d_conv_geom* g, int dtype);
+int64_t kd6d_wgrad_group_plan(const kd6d_wgrad_item* items, int n_items, int dtype, int n_workgroups, void* plan_host,
+                              int64_t plan_capacity, int32_t* info);
+int kd6d_wgrad_group_launch(const void* plan_dev, int n_workgroups, int n_reduce_blocks, float* slab_dev, void* stream);
+
 int kd6d_pack_dgrad_weights(int dtype, const void* w_base, void* wt_base,
                             const int32_t* desc_dev, int n_layers,
                             int total_blocks, void* stream);

@@ -38,6 +38,11 @@ class Levels(ctypes.Structure):
                 ("anchor_stride", ctypes.c_float * MAX_SEG), ("anchor_size", ctypes.c_float * MAX_SEG)]
 
 
+class WgradItem(ctypes.Structure):
+    _fields_ = [("geom", ConvGeom), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p),
+                ("dbias", ctypes.c_void_p)]
+
+
 MAX_GT = 4
 
 _P = ctypes.c_void_p
@@ -56,6 +61,9 @@ SIGNATURES = {
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],
+    "kd6d_wgrad_group_supported": [_G, _I],
+    "kd6d_wgrad_group_plan": [ctypes.POINTER(WgradItem), _I, _I, _I, _P, _I64, ctypes.POINTER(ctypes.c_int32)],
+    "kd6d_wgrad_group_launch": [_P, _I, _I, _P, _P],
     "kd6d_pack_dgrad_weights": [_I, _P, _P, _P, _I, _I, _P],
     "kd6d_colstats": [_I, _P, _I64, _I, _P, _P, _P],
     "kd6d_bn_train_fwd": [_I, _I, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
@@ -124,7 +132,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name.endswith("_workspace_floats") else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith(("_workspace_floats", "_group_plan")) else ctypes.c_int
     if lib.kd6d_abi_version() != ABI_VERSION:
         raise ImportError("libkd6d.so ABI version %d != expected %d" % (lib.kd6d_abi_version(), ABI_VERSION))
     return lib

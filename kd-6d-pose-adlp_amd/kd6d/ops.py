@@ -400,3 +400,70 @@ def sinkhorn_dense(x, alpha, y, beta, blur=0.05, scaling=0.5, reach=0.5, diamete
                                           reach if reach is not None else -1.0, float(max(diameter, 1e-12)), _ptr(ws), nws,
                                           _ptr(loss), _ptr(gx), _ptr(ga), _stream()), "kd6d_sinkhorn_dense_fwd_bwd")
     return loss, gx, ga
+
+
+# ---- grouped weight gradient (csrc/conv_wgrad_group.hip) -----------------------------------------------------
+def wgrad_group_supported(geom, dtype):
+    return bool(lib.kd6d_wgrad_group_supported(geom.ref, dt_code(dtype)))
+
+
+class WgradGroup:
+    """The weight gradients of several layers as one launch pair.  add() collects (geometry, x, dy, dw, dbias);
+    launch() plans the work list on first use (or when the set of tensors changed), keeps the plan and the
+    partial-tile slab on the device, and enqueues the two kernels on the current stream.  The collected tensors
+    must stay alive and unchanged until the launch has run (the engine's per-layer buffers are static)."""
+
+    def __init__(self, n_workgroups):
+        self.n_workgroups = int(n_workgroups)
+        self.items, self.flops = [], 0
+        self._key = None
+        self._plan = self._slab = self._info = None
+        self._keep = None
+
+    def add(self, geom, x, dy, dw, dbias=None, flops=0):
+        assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
+        assert x.dtype == dy.dtype == torch.bfloat16 and dw.dtype == torch.float32
+        assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
+        assert dbias is None or (dbias.dtype == torch.float32 and dbias.numel() >= geom.cout)
+        self.items.append((geom, x, dy, dw, dbias))
+        self.flops += flops
+
+    def __len__(self):
+        return len(self.items)
+
+    def _build(self, device):
+        n = len(self.items)
+        arr = (_lib.WgradItem * n)()
+        for i, (g, x, dy, dw, db) in enumerate(self.items):
+            ctypes.memmove(ctypes.byref(arr[i].geom), ctypes.byref(g.c), ctypes.sizeof(_lib.ConvGeom))
+            arr[i].x, arr[i].dy, arr[i].dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+            arr[i].dbias = db.data_ptr() if db is not None else None
+        info = (ctypes.c_int32 * 4)()
+        nbytes = lib.kd6d_wgrad_group_plan(arr, n, _lib.KD6D_BF16, self.n_workgroups, None, 0, info)
+        if nbytes < 0:
+            check(int(nbytes), "kd6d_wgrad_group_plan")
+        host = torch.zeros(int(nbytes), dtype=torch.uint8)
+        rc = lib.kd6d_wgrad_group_plan(arr, n, _lib.KD6D_BF16, self.n_workgroups, ctypes.c_void_p(host.data_ptr()),
+                                       int(nbytes), info)
+        if rc < 0:
+            check(int(rc), "kd6d_wgrad_group_plan")
+        self._plan = host.to(device)
+        slab_floats = int(info[2]) + (int(info[3]) << 31)
+        if self._slab is None or self._slab.numel() < slab_floats:
+            self._slab = torch.empty(slab_floats, dtype=torch.float32, device=device)
+        self._info = (int(info[0]), int(info[1]))
+        self._keep = list(self.items)
+
+    def launch(self):
+        """Enqueue on the current stream; clears the collected items."""
+        if not self.items:
+            return
+        key = tuple((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), g.rows_out)
+                    for g, x, dy, dw, db in self.items)
+        if key != self._key:
+            self._build(self.items[0][1].device)
+            self._key = key
+        with _Timed("conv_wgrad", self.flops, self.items[0][0]):
+            check(lib.kd6d_wgrad_group_launch(_ptr(self._plan), self._info[0], self._info[1], _ptr(self._slab),
+                                              _stream()), "kd6d_wgrad_group_launch")
+        self.items, self.flops = [], 0

@@ -859,3 +859,47 @@ def test_fused_clip_adamw_matches_torch(gpu_device):
                                       1e-4, it + 1, None, None, ops._stream()))
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), z["params"][it], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,C,levels,n_wg", [
+    (2, 128, [(32, 32), (16, 16), (8, 8), (4, 4)], 64),      # the student head's level set, short splits
+    (16, 128, [(32, 32), (16, 16), (8, 8), (4, 4)], 256),    # ... at the benchmark batch, one workgroup per CU
+    (3, 256, [(9, 7), (5, 3), (2, 1)], 40),                  # odd maps, two 128-channel chunks, ragged steps
+])
+def test_wgrad_group_matches_torch(gpu_device, B, C, levels, n_wg):
+    """ops.WgradGroup: the weight (and bias) gradients of a tower layer, the 240-channel pose layer, the 16-channel
+    cls layer and a 1x1 layer in ONE launch pair, vs torch's conv2d_weight per layer.  bf16-representable inputs,
+    fp32 accumulation: only the summation order differs (2e-4 of the tensor scale).  The call accumulates (+=)."""
+    ops = _ops()
+    dev = gpu_device
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(B * 7 + C)
+    group = ops.WgradGroup(n_wg)
+    cases = []
+    for cout, k, bias in ((C, 3, True), (240, 3, True), (16, 3, True), (C, 1, False), (24, 1, True)):
+        geom = ops.Geom(B, C, cout, k, 1, k // 2, levels)
+        assert ops.wgrad_group_supported(geom, dtype)
+        xs = [round_to(torch.randn(B, C, h, w, generator=g), dtype) for (h, w) in levels]
+        dys = [round_to(torch.randn(B, cout, h, w, generator=g), dtype) for (h, w) in levels]
+        dw = torch.full((cout, k, k, C), 0.25, dtype=torch.float32, device=dev)
+        db = torch.full((cout,), 0.5, dtype=torch.float32, device=dev) if bias else None
+        xp, dyp = pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev)
+        group.add(geom, xp, dyp, dw, db)
+        cases.append((cout, k, xs, dys, dw, db))
+    assert not ops.wgrad_group_supported(ops.Geom(B, C, C, 3, 2, 1, levels), dtype)          # stride 2
+    assert not ops.wgrad_group_supported(ops.Geom(B, 64, C, 3, 1, 1, levels), dtype)         # cin % 128
+    group.launch()
+    assert len(group) == 0
+    torch.cuda.synchronize()
+    for cout, k, xs, dys, dw, db in cases:
+        ref = torch.zeros(cout, C, k, k)
+        ref_b = torch.zeros(cout, dtype=torch.float64)
+        for x, dy in zip(xs, dys):
+            ref += torch.nn.grad.conv2d_weight(x, (cout, C, k, k), dy, stride=1, padding=k // 2)
+            ref_b += dy.double().sum(dim=(0, 2, 3))
+        got = dw.cpu().permute(0, 3, 1, 2) - 0.25
+        scale = max(float(ref.abs().max()), 1.0)
+        torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: "cout %d k %d: %s" % (cout, k, m))
+        if db is not None:
+            torch.testing.assert_close(db.cpu().double() - 0.5, ref_b, rtol=2e-4,
+                                       atol=2e-4 * max(float(ref_b.abs().max()), 1.0))
