@@ -179,12 +179,19 @@ class Conv:
                               residual=residual, seg_scale=seg_scale, out_f32=out_f32, flops=self.flops(g),
                               stats=stats, stats_groups=stats_groups, workspace=self.net.workspace()), g
 
-    def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False):
+    def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False, need_dw=True):
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
         st = self.net.store
         g = self.geom(batch, levels)
-        side = self.net.next_side_stream()
-        if side is None:
+        grp = self.net.wgrad_group if self.net.grouping else None
+        if not need_dw:
+            pass
+        elif grp is not None and x.dtype == torch.bfloat16 and ops.wgrad_group_supported(g, x.dtype):
+            # collected: one launch pair for the whole network section (PoseNet.flush_wgrad_group); x and dy are
+            # per-layer buffers that stay untouched until the sweep has joined its side streams
+            grp.add(g, x, dy, st.storage(self.w, "grads"), None if self.b is None else st.storage(self.b, "grads"),
+                    flops=self.flops(g))
+        elif (side := self.net.next_side_stream()) is None:
             ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
                              dbias=None if self.b is None else st.storage(self.b, "grads"))
         else:
@@ -344,6 +351,13 @@ class PoseNet:
         self.side_stream = None        # set (e.g. by GraphedKDStep) to run weight gradients concurrently
         self.side_streams = None       # optional list: consecutive weight gradients rotate over these streams
         self.wgrad_cu_budget = 0       # CUs each forked weight gradient aims to fill (0 = the device)
+        # the weight gradients of the head and FPN output convolutions as ONE grouped launch per step
+        # (csrc/conv_wgrad_group.hip); created on first use, bf16 only.  wgrad_group_wgs: workgroups of that launch
+        # (0 = one per CU)
+        self.wgrad_group = None
+        self.grouping = False          # True while the reverse sweep is inside the section whose dW are collected
+        self.use_wgrad_group = True
+        self.wgrad_group_wgs = 0
         self.fuse_pool = os.environ.get("KD6D_FUSE_POOL", "1") != "0"   # BN + act + maxpool as one kernel (training)
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
         self.pair_towers = int(os.environ.get("KD6D_PAIR_TOWERS", "1"))
@@ -488,6 +502,19 @@ class PoseNet:
             self._side_rr = (self._side_rr + 1) % len(self.side_streams)
             return self.side_streams[self._side_rr]
         return self.side_stream
+
+    def flush_wgrad_group(self):
+        """Launch the collected weight gradients (on a side stream when there is one: nothing in the sweep reads dW)."""
+        grp = self.wgrad_group
+        if grp is None or len(grp) == 0:
+            return
+        side = self.next_side_stream()
+        if side is None:
+            grp.launch()
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            grp.launch()
 
     def workspace(self):
         ws = self._bufs.get("__workspace__")
@@ -672,6 +699,9 @@ class PoseNet:
         (the Scale module's factor is already folded into dreg by kd6d_loss_backward)."""
         assert self.training and self.arch != "darknet53"
         B, lv_all, r, oc = self.batch, self.levels, self.rows, self.out_channel
+        if self.use_wgrad_group and self.dtype == torch.bfloat16 and self.wgrad_group is None:
+            self.wgrad_group = ops.WgradGroup(self.wgrad_group_wgs or ops.device_cu_count())
+        self.grouping = self.wgrad_group is not None
         d_head_in = self.buf("d_head_in", (r, oc))
         first = True
         towers = (("cls", self.cls_tower, self.cls_logits, dcls), ("pose", self.pose_tower, self.pose_pred, dreg))
@@ -719,6 +749,21 @@ class PoseNet:
 
         idxs = sorted(self.inner.keys())
         n_l = len(idxs)
+        # d_head_in is complete: the FPN output convolutions' weight gradients (x = the top-down sums kept by the
+        # forward, dy = the level slices of d_head_in) join the head's group, which then goes out as one launch pair
+        grouped_out = set()
+        if self.wgrad_group is not None:
+            for pos in range(n_l):
+                i = idxs[pos]
+                f, lv, inner = self.fpn_ctx[i]
+                conv = self.outc[i]
+                g = conv.geom(B, lv)
+                if ops.wgrad_group_supported(g, inner.dtype):
+                    self.wgrad_group.add(g, inner, dslot(pos), self.store.storage(conv.w, "grads"),
+                                         self.store.storage(conv.b, "grads"), flops=conv.flops(g))
+                    grouped_out.add(i)
+            self.flush_wgrad_group()
+        self.grouping = False
         # P7 = conv(relu(P6)); P6 = conv(top feature)
         ftop, lvtop, p6, p6r, h6 = self.p6_ctx
         d_p6r = self.p7.bwd(p6r, dslot(n_l + 1), B, [h6], dx=self.buf("d_p6r", p6.shape))
@@ -735,9 +780,9 @@ class PoseNet:
             d_inner = self.buf("d_inner%d" % i, inner.shape)
             if d_inner_up is not None:
                 ops.sumpool2(d_inner_up[0], d_inner, B, d_inner_up[1], d_inner_up[2])
-                self.outc[i].bwd(inner, dslot(pos), B, lv, dx=d_inner, accumulate=True)
+                self.outc[i].bwd(inner, dslot(pos), B, lv, dx=d_inner, accumulate=True, need_dw=i not in grouped_out)
             else:
-                self.outc[i].bwd(inner, dslot(pos), B, lv, dx=d_inner)
+                self.outc[i].bwd(inner, dslot(pos), B, lv, dx=d_inner, need_dw=i not in grouped_out)
             if i == top:
                 self.inner[i].bwd(f, d_inner, B, lv, dx=dfeat[top], accumulate=True)
             else:
