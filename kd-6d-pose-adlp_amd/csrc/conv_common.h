@@ -1,0 +1,488 @@
+// Shared by the convolution kernels of libkd6d.so (conv_igemm.hip: register-staged / LDS-DMA / resident-patch /
+// weight-gradient kernels; conv_halo.hip: the 3x3 halo-patch kernel): GEMM geometry, LDS tile image, fragment
+// loads, the common epilogue with its fused normalisation statistics, LDS-DMA helpers and the host-side geometry
+// checks.  Everything is static / inline: each translation unit gets its own copy.
+#pragma once
+#include <math.h>
+#include <stdlib.h>
+
+#include "kd6d_common.h"
+
+namespace kd6d_detail {
+
+
+constexpr int kMaxSeg = KD6D_MAX_SEG;
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct SegDev {
+  int src_h, src_w;    // gather-source grid
+  int dst_h, dst_w;    // destination grid (rows of the GEMM)
+  int src_row0;        // first source row of the level
+  int dst_row0;        // first destination row of the level
+  int m_begin;         // first GEMM row index of the level
+  int dst_hw;
+  float inv_hw, inv_w; // 1 / dst_hw, 1 / dst_w: row decode without integer division (GEMM rows < 2^24)
+};
+
+// floor(x / d) for 0 <= x < 2^24 from inv = 1.0f / d: float estimate, one correction step either way
+__device__ __forceinline__ int fast_div(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  q += ((q + 1) * d <= x) ? 1 : 0;
+  q -= (q * d > x) ? 1 : 0;
+  return q;
+}
+
+struct ConvParams {
+  int nseg, batch;
+  int C;       // gather-source channels (k granularity)
+  int N;       // result channels
+  int ks, stride, pad;
+  int K;       // ks*ks*C
+  int M;       // total destination pixels
+  int n_ctiles;
+  int n_ptiles;
+  int p_fastest;   // workgroup order: pixel tiles fastest (weight tile shared inside an XCD) instead of channel tiles
+  SegDev seg[kMaxSeg];
+  const void* src;
+  const void* wgt;
+  void* dst;
+  const float* ch_scale;
+  const float* ch_shift;
+  const void* residual;
+  const float* seg_scale;
+  int act;
+  int out_f32;
+  float* stats;        // optional fused statistics of the stored values (see conv_epilogue_stats)
+  int stats_groups;    // 0: per channel {sum[N], sumsq[N]} (BatchNorm); G > 0: {sum, sumsq} per (level, image, group)
+  float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
+  int nk_split;        // k-steps per split
+  int stats_cpg_shift; // log2(channels per group): 2 or 3
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  static constexpr int CHUNKS = 2;  // 32-deep chunks per 128-B row
+  bf16x8_t v;
+};
+template <> struct Frag<float> {
+  static constexpr int CHUNKS = 1;
+  f32x4_t lo, hi;
+};
+
+__device__ __forceinline__ int lds_off(int row, int gran) {
+  return row * 128 + ((gran ^ (row & 7)) << 4);
+}
+
+template <typename T>
+__device__ __forceinline__ void load_frag(const char* tile, int row, int chunk, int q, Frag<T>& f);
+template <>
+__device__ __forceinline__ void load_frag<bf16_t>(const char* tile, int row, int chunk, int q,
+                                                  Frag<bf16_t>& f) {
+  f.v = *reinterpret_cast<const bf16x8_t*>(tile + lds_off(row, chunk * 4 + q));
+}
+template <>
+__device__ __forceinline__ void load_frag<float>(const char* tile, int row, int /*chunk*/, int q,
+                                                 Frag<float>& f) {
+  f.lo = *reinterpret_cast<const f32x4_t*>(tile + lds_off(row, 2 * q));
+  f.hi = *reinterpret_cast<const f32x4_t*>(tile + lds_off(row, 2 * q + 1));
+}
+
+__device__ __forceinline__ void mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<float>& a, const Frag<float>& b, f32x4_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[0], b.lo[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[1], b.lo[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[2], b.lo[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[3], b.lo[3], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[0], b.hi[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[1], b.hi[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[2], b.hi[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[3], b.hi[3], acc, 0, 0, 0);
+}
+
+// XCD-aware, bijective remap of the linear workgroup id: consecutive remapped ids
+// (which share an input pixel tile) land on one XCD / one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Decode GEMM row m -> (level fields) without dynamic indexing of the kernarg table.
+struct RowInfo {
+  int y, x;        // destination coordinates
+  int src_h, src_w;
+  int src_base;    // source row of (b, 0, 0)
+  int dst_row;
+  int seg;
+};
+__device__ __forceinline__ RowInfo decode_row(const ConvParams& p, int m) {
+  RowInfo r;
+  int mb = 0, hw = 1, dw = 1, sh = 0, sw = 0, s0 = 0, d0 = 0, sg = 0;
+  float ihw = 1.f, iw = 1.f;
+#pragma unroll
+  for (int s = 0; s < kMaxSeg; ++s) {
+    if (s < p.nseg && m >= p.seg[s].m_begin) {
+      mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; dw = p.seg[s].dst_w;
+      sh = p.seg[s].src_h; sw = p.seg[s].src_w; s0 = p.seg[s].src_row0;
+      d0 = p.seg[s].dst_row0; sg = s; ihw = p.seg[s].inv_hw; iw = p.seg[s].inv_w;
+    }
+  }
+  const int local = m - mb;
+  const int b = fast_div(local, hw, ihw);
+  const int rem = local - b * hw;
+  r.y = fast_div(rem, dw, iw);
+  r.x = rem - r.y * dw;
+  r.src_h = sh; r.src_w = sw;
+  r.src_base = s0 + b * sh * sw;
+  r.dst_row = d0 + local;
+  r.seg = sg;
+  if (m >= p.M) { r.src_h = 0; r.src_w = 0; }
+  return r;
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane.  VALU-only (v_add_f32
+// with dpp modifiers): the ds_bpermute form of __shfl_xor costs an LDS round trip per step.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// Fused normalisation statistics of a conv output (replaces a separate pass over the fp32 tensor).
+// acc holds the FINAL values (what was stored).  Per-channel mode (BatchNorm batch statistics):
+// registers -> 16-lane shuffle -> LDS (one slot per channel of the tile) -> one global atomic per
+// channel and workgroup.  Group mode (GroupNorm): a 16-pixel fragment normally lies inside one
+// (level, image); its 4-channel lane sums are shuffled down to one atomic pair per group, else
+// (tiny levels, several images per fragment) every lane adds its own 4-channel partial.
+template <int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
+                                                    int m0, int n0, int wp, int wc, int lane, float* red) {
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  if (p.stats_groups == 0) {
+    __syncthreads();                       // staging buffers are dead from here on
+    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < PI; ++q) {
+        const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+        const bool ok = m < p.M && n0 + nl < p.N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = ok ? acc[c][q][r] : 0.f;
+          s1[r] += v;
+          s2[r] += v * v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] = row16_sum(s1[r]);
+        s2[r] = row16_sum(s2[r]);
+      }
+      if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(&red[nl + r], s1[r]);
+          atomicAdd(&red[BC + nl + r], s2[r]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
+      const int which = i / BC, nl = i - which * BC;
+      if (n0 + nl < p.N) atomicAdd(p.stats + (size_t)which * p.N + n0 + nl, red[i]);
+    }
+    return;
+  }
+  // ---- group mode: LDS table [image of the tile][group of the tile] -> one full-width flush ----
+  const int G = p.stats_groups;
+  const int cs = p.stats_cpg_shift;        // 4 or 8 channels per group: a lane's 4 aligned channels share one
+  const int GT = BC >> cs;                 // groups touched by this channel tile
+  auto key_of = [&](int m) {
+    int mb = 0, hw = 1, sg = 0;
+    float inv = 1.f;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s)
+      if (s < p.nseg && m >= p.seg[s].m_begin) {
+        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg[s].inv_hw;
+      }
+    // (m - mb) / hw without an integer division (operands < 2^24): float estimate, then one correction step
+    const int xx = m - mb;
+    int b = (int)((float)xx * inv);
+    b += ((b + 1) * hw <= xx) ? 1 : 0;
+    b -= (b * hw > xx) ? 1 : 0;
+    return sg * p.batch + b;               // monotone in m: levels are packed level-major, image-major
+  };
+  const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
+  const int key_lo = key_of(m0);
+  const int nkeys = key_of(m_last) - key_lo + 1;
+  const int tab = nkeys * GT * 2;          // <= BP * BC / 2 floats: fits the dead staging buffers
+  __syncthreads();
+  for (int i = threadIdx.x; i < tab; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  // a 16-pixel fragment normally lies inside one image: DPP row sum, one writer lane per 4-channel slice;
+  // otherwise (tiny levels, several images per fragment) every lane adds its own partial
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+    const bool mok = m < p.M;
+    const int key = mok ? key_of(m) - key_lo : 0;
+    const int key0 = __shfl(key, lane & 48, 64);
+    const bool uniform = __all(!mok || key == key0);     // rows past M sit at the tail of the last fragment
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+      const bool ok = mok && n0 + nl < p.N;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ok ? acc[c][q][r] : 0.f;
+        s1 += v;
+        s2 += v * v;
+      }
+      if (uniform) {
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (fr == 0 && n0 + nl < p.N) {
+          float* o2 = red + ((key0 * GT + (nl >> cs)) << 1);
+          atomicAdd(o2, s1);
+          atomicAdd(o2 + 1, s2);
+        }
+      } else if (ok) {
+        float* o2 = red + ((key * GT + (nl >> cs)) << 1);
+        atomicAdd(o2, s1);
+        atomicAdd(o2 + 1, s2);
+      }
+    }
+  }
+  __syncthreads();
+  const int g_first = n0 >> cs;
+  const int gts = 31 - __clz(GT * 2);      // GT * 2 is a power of two
+  for (int i = threadIdx.x; i < tab; i += blockDim.x) {
+    const int k = i >> gts, rem = i & (GT * 2 - 1);
+    const int gl = rem >> 1;
+    if (g_first + gl < G) atomicAdd(p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1), red[i]);
+  }
+}
+
+// Epilogue shared by the register-staged and the LDS-DMA kernels: lane owns pixel (lane&15),
+// channels (lane>>4)*4 .. +3 of every 16x16 accumulator tile.
+template <typename T, int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
+                                              int m0, int n0, int wp, int wc, int lane, float* smem_f32) {
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const bool vec_ok = (p.N & 3) == 0;
+  // per-channel epilogue parameters of this lane's channels, loaded ONCE (they do not depend on the pixel):
+  // identity where absent, so the pixel loop below is branch-free in them
+  constexpr bool HOIST = CI <= 4;
+  f32x4_t hsc[HOIST ? CI : 1], hsh[HOIST ? CI : 1];
+  if (HOIST && vec_ok) {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
+      hsc[c] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+      hsh[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) {
+        if (p.ch_scale) hsc[c] = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+        if (p.ch_shift) hsh[c] = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+    if (m >= p.M) continue;
+    int drow = m, sg = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) {
+      if (s < p.nseg && m >= p.seg[s].m_begin) {
+        drow = p.seg[s].dst_row0 + (m - p.seg[s].m_begin);
+        sg = s;
+      }
+    }
+    float sscale = 1.f;
+    if (p.seg_scale) sscale = p.seg_scale[sg];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]};
+      const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
+      if (vec_ok) {
+        if (HOIST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * hsc[c][r] + hsh[c][r];
+        } else {
+          if (p.ch_scale) {
+            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= s4[r];
+          }
+          if (p.ch_shift) {
+            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += s4[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= sscale;
+          if (p.act == KD6D_ACT_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+          else if (p.act == KD6D_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.residual) {
+          if (p.out_f32) {
+            const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(
+                reinterpret_cast<const float*>(p.residual) + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += r4[r];
+          } else {
+            const T* rp = reinterpret_cast<const T*>(p.residual) + o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+          }
+        }
+        if (p.stats) acc[c][q] = f32x4_t{v[0], v[1], v[2], v[3]};
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
+              f32x4_t{v[0], v[1], v[2], v[3]};
+        } else if (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
+              f32x4_t{v[0], v[1], v[2], v[3]};
+        } else {
+          u32x2_t pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.N) continue;
+          float t = v[r];
+          if (p.ch_scale) t *= p.ch_scale[n + r];
+          if (p.ch_shift) t += p.ch_shift[n + r];
+          t *= sscale;
+          if (p.act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+          else if (p.act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+          if (p.residual) {
+            t += p.out_f32 ? reinterpret_cast<const float*>(p.residual)[o + r]
+                           : to_f32<T>(reinterpret_cast<const T*>(p.residual)[o + r]);
+          }
+          if (p.out_f32) reinterpret_cast<float*>(p.dst)[o + r] = t;
+          else reinterpret_cast<T*>(p.dst)[o + r] = from_f32<T>(t);
+        }
+      }
+    }
+  }
+  if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
+}
+
+
+static __device__ const uint4 kd6d_zero_page[4] = {};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline bool fill_segs(const kd6d_conv_geom* g, bool dgrad, SegDev* seg, int* M_out) {
+  int m = 0;
+  for (int s = 0; s < g->nseg; ++s) {
+    const kd6d_seg& gs = g->seg[s];
+    SegDev& d = seg[s];
+    if (!dgrad) {
+      d.src_h = gs.in_h; d.src_w = gs.in_w; d.dst_h = gs.out_h; d.dst_w = gs.out_w;
+      d.src_row0 = gs.in_row0; d.dst_row0 = gs.out_row0;
+    } else {
+      d.src_h = gs.out_h; d.src_w = gs.out_w; d.dst_h = gs.in_h; d.dst_w = gs.in_w;
+      d.src_row0 = gs.out_row0; d.dst_row0 = gs.in_row0;
+    }
+    d.dst_hw = d.dst_h * d.dst_w;
+    d.inv_hw = 1.0f / (float)d.dst_hw;
+    d.inv_w = 1.0f / (float)d.dst_w;
+    d.m_begin = m;
+    if (d.src_h > 32767 || d.src_w > 32767 || d.src_h < 0 || d.src_w < 0) return false;
+    if ((long long)m + (long long)g->batch * d.dst_hw >= (1ll << 24)) return false;   // fast_div range
+    m += g->batch * d.dst_hw;
+  }
+  *M_out = m;
+  return true;
+}
+
+static inline int check_geom(const kd6d_conv_geom* g, int dtype, const char* who) {
+  KD6D_CHECK_ARG(g != nullptr, "%s: null geometry", who);
+  KD6D_CHECK_ARG(g->nseg >= 1 && g->nseg <= kMaxSeg, "%s: nseg=%d out of range", who, g->nseg);
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "%s: bad dtype %d", who, dtype);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(g->cin > 0 && g->cin % eg == 0, "%s: cin=%d must be a multiple of %d", who, g->cin, eg);
+  KD6D_CHECK_ARG(g->cout > 0, "%s: cout=%d", who, g->cout);
+  KD6D_CHECK_ARG(g->ksize >= 1 && g->ksize <= 7 && g->stride >= 1 && g->stride <= 4 && g->pad >= 0,
+                 "%s: bad ksize/stride/pad %d/%d/%d", who, g->ksize, g->stride, g->pad);
+  KD6D_CHECK_ARG(g->batch >= 1, "%s: batch=%d", who, g->batch);
+  for (int s = 0; s < g->nseg; ++s) {
+    const kd6d_seg& q = g->seg[s];
+    KD6D_CHECK_ARG(q.in_h > 0 && q.in_w > 0 && q.out_h > 0 && q.out_w > 0, "%s: empty level %d", who, s);
+    KD6D_CHECK_ARG(q.out_h == (q.in_h + 2 * g->pad - g->ksize) / g->stride + 1 &&
+                       q.out_w == (q.in_w + 2 * g->pad - g->ksize) / g->stride + 1,
+                   "%s: level %d output grid %dx%d inconsistent with input %dx%d", who, s, q.out_h,
+                   q.out_w, q.in_h, q.in_w);
+  }
+  return KD6D_OK;
+}
+
+// Workgroup order.  After the XCD remap an XCD runs a CONTIGUOUS range of ~1/8 of the tile ids, so the
+// fastest-varying tile index decides which operand that XCD's 4 MiB L2 can keep: channel tiles fastest
+// -> the XCD touches few pixel tiles but ALL weights; pixel tiles fastest -> few weight tiles but many
+// pixels.  Pick the order with the smaller per-XCD footprint (small-M / wide-N layers: weights).
+static inline void set_tile_order(ConvParams& q, int ptiles, int BP, int BC) {
+  q.n_ptiles = ptiles;
+  static const int force = []() {
+    const char* e = getenv("KD6D_CONV_ORDER");
+    return e ? atoi(e) : -1;
+  }();
+  const double tiles = (double)ptiles * q.n_ctiles;
+  const double per_xcd = tiles / 8.0;
+  const double w_tile = (double)BC * q.K * 2.0, x_tile = (double)BP * q.C * 2.0 * (q.ks > 1 ? 1.5 : 1.0);
+  // channel tiles fastest: an XCD spans per_xcd / n_ctiles pixel tiles (>= 1) and min(per_xcd, n_ctiles) weight tiles
+  auto foot = [&](double n_fast, double t_fast, double t_slow) {
+    const double fast = per_xcd < n_fast ? per_xcd : n_fast;
+    const double slow = per_xcd / n_fast < 1.0 ? 1.0 : per_xcd / n_fast;
+    return fast * t_fast + slow * t_slow;
+  };
+  const double c_fast = foot(q.n_ctiles, w_tile, x_tile);
+  const double p_fast = foot(ptiles, x_tile, w_tile);
+  q.p_fastest = p_fast < c_fast ? 1 : 0;
+  if (force >= 0) q.p_fastest = force;
+}
+
+static inline int cached_cu_count() {       // one device per process
+  static const int n = []() { const int c = kd6d_device_cu_count(); return c > 0 ? c : 256; }();
+  return n;
+}
+
+// conv_halo.hip: the 3x3 / stride 1 halo-patch kernel takes the layer (returns false: not its shape / too few tiles)
+bool dispatch_halo_fwd(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st);
+bool dispatch_halo_dgrad(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st);
+
+}  // namespace kd6d_detail

@@ -18,392 +18,11 @@
 //   bf16: v_mfma_f32_16x16x32_bf16, one granule per lane per 32-deep chunk.
 //   fp32: v_mfma_f32_16x16x4_f32 x8 on a 32-deep chunk; lane group q holds
 //         k = 8q..8q+7 (two granules) and MFMA j contracts {8q+j}: exact fp32.
-#include <math.h>
-#include <stdlib.h>
+#include "conv_common.h"
 
-#include "kd6d_common.h"
+using namespace kd6d_detail;
 
 namespace {
-
-constexpr int kMaxSeg = KD6D_MAX_SEG;
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-
-struct SegDev {
-  int src_h, src_w;    // gather-source grid
-  int dst_h, dst_w;    // destination grid (rows of the GEMM)
-  int src_row0;        // first source row of the level
-  int dst_row0;        // first destination row of the level
-  int m_begin;         // first GEMM row index of the level
-  int dst_hw;
-  float inv_hw, inv_w; // 1 / dst_hw, 1 / dst_w: row decode without integer division (GEMM rows < 2^24)
-};
-
-// floor(x / d) for 0 <= x < 2^24 from inv = 1.0f / d: float estimate, one correction step either way
-__device__ __forceinline__ int fast_div(int x, int d, float inv) {
-  int q = (int)((float)x * inv);
-  q += ((q + 1) * d <= x) ? 1 : 0;
-  q -= (q * d > x) ? 1 : 0;
-  return q;
-}
-
-struct ConvParams {
-  int nseg, batch;
-  int C;       // gather-source channels (k granularity)
-  int N;       // result channels
-  int ks, stride, pad;
-  int K;       // ks*ks*C
-  int M;       // total destination pixels
-  int n_ctiles;
-  int n_ptiles;
-  int p_fastest;   // workgroup order: pixel tiles fastest (weight tile shared inside an XCD) instead of channel tiles
-  SegDev seg[kMaxSeg];
-  const void* src;
-  const void* wgt;
-  void* dst;
-  const float* ch_scale;
-  const float* ch_shift;
-  const void* residual;
-  const float* seg_scale;
-  int act;
-  int out_f32;
-  float* stats;        // optional fused statistics of the stored values (see conv_epilogue_stats)
-  int stats_groups;    // 0: per channel {sum[N], sumsq[N]} (BatchNorm); G > 0: {sum, sumsq} per (level, image, group)
-  float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
-  int nk_split;        // k-steps per split
-  int stats_cpg_shift; // log2(channels per group): 2 or 3
-};
-
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> {
-  static constexpr int CHUNKS = 2;  // 32-deep chunks per 128-B row
-  bf16x8_t v;
-};
-template <> struct Frag<float> {
-  static constexpr int CHUNKS = 1;
-  f32x4_t lo, hi;
-};
-
-__device__ __forceinline__ int lds_off(int row, int gran) {
-  return row * 128 + ((gran ^ (row & 7)) << 4);
-}
-
-template <typename T>
-__device__ __forceinline__ void load_frag(const char* tile, int row, int chunk, int q, Frag<T>& f);
-template <>
-__device__ __forceinline__ void load_frag<bf16_t>(const char* tile, int row, int chunk, int q,
-                                                  Frag<bf16_t>& f) {
-  f.v = *reinterpret_cast<const bf16x8_t*>(tile + lds_off(row, chunk * 4 + q));
-}
-template <>
-__device__ __forceinline__ void load_frag<float>(const char* tile, int row, int /*chunk*/, int q,
-                                                 Frag<float>& f) {
-  f.lo = *reinterpret_cast<const f32x4_t*>(tile + lds_off(row, 2 * q));
-  f.hi = *reinterpret_cast<const f32x4_t*>(tile + lds_off(row, 2 * q + 1));
-}
-
-__device__ __forceinline__ void mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4_t& acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
-}
-__device__ __forceinline__ void mma(const Frag<float>& a, const Frag<float>& b, f32x4_t& acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[0], b.lo[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[1], b.lo[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[2], b.lo[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[3], b.lo[3], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[0], b.hi[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[1], b.hi[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[2], b.hi[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[3], b.hi[3], acc, 0, 0, 0);
-}
-
-// XCD-aware, bijective remap of the linear workgroup id: consecutive remapped ids
-// (which share an input pixel tile) land on one XCD / one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// Decode GEMM row m -> (level fields) without dynamic indexing of the kernarg table.
-struct RowInfo {
-  int y, x;        // destination coordinates
-  int src_h, src_w;
-  int src_base;    // source row of (b, 0, 0)
-  int dst_row;
-  int seg;
-};
-__device__ __forceinline__ RowInfo decode_row(const ConvParams& p, int m) {
-  RowInfo r;
-  int mb = 0, hw = 1, dw = 1, sh = 0, sw = 0, s0 = 0, d0 = 0, sg = 0;
-  float ihw = 1.f, iw = 1.f;
-#pragma unroll
-  for (int s = 0; s < kMaxSeg; ++s) {
-    if (s < p.nseg && m >= p.seg[s].m_begin) {
-      mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; dw = p.seg[s].dst_w;
-      sh = p.seg[s].src_h; sw = p.seg[s].src_w; s0 = p.seg[s].src_row0;
-      d0 = p.seg[s].dst_row0; sg = s; ihw = p.seg[s].inv_hw; iw = p.seg[s].inv_w;
-    }
-  }
-  const int local = m - mb;
-  const int b = fast_div(local, hw, ihw);
-  const int rem = local - b * hw;
-  r.y = fast_div(rem, dw, iw);
-  r.x = rem - r.y * dw;
-  r.src_h = sh; r.src_w = sw;
-  r.src_base = s0 + b * sh * sw;
-  r.dst_row = d0 + local;
-  r.seg = sg;
-  if (m >= p.M) { r.src_h = 0; r.src_w = 0; }
-  return r;
-}
-
-// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane.  VALU-only (v_add_f32
-// with dpp modifiers): the ds_bpermute form of __shfl_xor costs an LDS round trip per step.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-  return v;
-}
-
-// Fused normalisation statistics of a conv output (replaces a separate pass over the fp32 tensor).
-// acc holds the FINAL values (what was stored).  Per-channel mode (BatchNorm batch statistics):
-// registers -> 16-lane shuffle -> LDS (one slot per channel of the tile) -> one global atomic per
-// channel and workgroup.  Group mode (GroupNorm): a 16-pixel fragment normally lies inside one
-// (level, image); its 4-channel lane sums are shuffled down to one atomic pair per group, else
-// (tiny levels, several images per fragment) every lane adds its own 4-channel partial.
-template <int BP, int BC, int WP, int WC>
-__device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
-                                                    int m0, int n0, int wp, int wc, int lane, float* red) {
-  constexpr int PI = BP / WP / 16;
-  constexpr int CI = BC / WC / 16;
-  const int fr = lane & 15;
-  const int fq = lane >> 4;
-  if (p.stats_groups == 0) {
-    __syncthreads();                       // staging buffers are dead from here on
-    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CI; ++c) {
-      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < PI; ++q) {
-        const int m = m0 + wp * (BP / WP) + q * 16 + fr;
-        const bool ok = m < p.M && n0 + nl < p.N;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = ok ? acc[c][q][r] : 0.f;
-          s1[r] += v;
-          s2[r] += v * v;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s1[r] = row16_sum(s1[r]);
-        s2[r] = row16_sum(s2[r]);
-      }
-      if (fr == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(&red[nl + r], s1[r]);
-          atomicAdd(&red[BC + nl + r], s2[r]);
-        }
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
-      const int which = i / BC, nl = i - which * BC;
-      if (n0 + nl < p.N) atomicAdd(p.stats + (size_t)which * p.N + n0 + nl, red[i]);
-    }
-    return;
-  }
-  // ---- group mode: LDS table [image of the tile][group of the tile] -> one full-width flush ----
-  const int G = p.stats_groups;
-  const int cs = p.stats_cpg_shift;        // 4 or 8 channels per group: a lane's 4 aligned channels share one
-  const int GT = BC >> cs;                 // groups touched by this channel tile
-  auto key_of = [&](int m) {
-    int mb = 0, hw = 1, sg = 0;
-    float inv = 1.f;
-#pragma unroll
-    for (int s = 0; s < kMaxSeg; ++s)
-      if (s < p.nseg && m >= p.seg[s].m_begin) {
-        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg[s].inv_hw;
-      }
-    // (m - mb) / hw without an integer division (operands < 2^24): float estimate, then one correction step
-    const int xx = m - mb;
-    int b = (int)((float)xx * inv);
-    b += ((b + 1) * hw <= xx) ? 1 : 0;
-    b -= (b * hw > xx) ? 1 : 0;
-    return sg * p.batch + b;               // monotone in m: levels are packed level-major, image-major
-  };
-  const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
-  const int key_lo = key_of(m0);
-  const int nkeys = key_of(m_last) - key_lo + 1;
-  const int tab = nkeys * GT * 2;          // <= BP * BC / 2 floats: fits the dead staging buffers
-  __syncthreads();
-  for (int i = threadIdx.x; i < tab; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
-  // a 16-pixel fragment normally lies inside one image: DPP row sum, one writer lane per 4-channel slice;
-  // otherwise (tiny levels, several images per fragment) every lane adds its own partial
-#pragma unroll
-  for (int q = 0; q < PI; ++q) {
-    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
-    const bool mok = m < p.M;
-    const int key = mok ? key_of(m) - key_lo : 0;
-    const int key0 = __shfl(key, lane & 48, 64);
-    const bool uniform = __all(!mok || key == key0);     // rows past M sit at the tail of the last fragment
-#pragma unroll
-    for (int c = 0; c < CI; ++c) {
-      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
-      const bool ok = mok && n0 + nl < p.N;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = ok ? acc[c][q][r] : 0.f;
-        s1 += v;
-        s2 += v * v;
-      }
-      if (uniform) {
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if (fr == 0 && n0 + nl < p.N) {
-          float* o2 = red + ((key0 * GT + (nl >> cs)) << 1);
-          atomicAdd(o2, s1);
-          atomicAdd(o2 + 1, s2);
-        }
-      } else if (ok) {
-        float* o2 = red + ((key * GT + (nl >> cs)) << 1);
-        atomicAdd(o2, s1);
-        atomicAdd(o2 + 1, s2);
-      }
-    }
-  }
-  __syncthreads();
-  const int g_first = n0 >> cs;
-  const int gts = 31 - __clz(GT * 2);      // GT * 2 is a power of two
-  for (int i = threadIdx.x; i < tab; i += blockDim.x) {
-    const int k = i >> gts, rem = i & (GT * 2 - 1);
-    const int gl = rem >> 1;
-    if (g_first + gl < G) atomicAdd(p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1), red[i]);
-  }
-}
-
-// Epilogue shared by the register-staged and the LDS-DMA kernels: lane owns pixel (lane&15),
-// channels (lane>>4)*4 .. +3 of every 16x16 accumulator tile.
-template <typename T, int BP, int BC, int WP, int WC>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
-                                              int m0, int n0, int wp, int wc, int lane, float* smem_f32) {
-  constexpr int PI = BP / WP / 16;
-  constexpr int CI = BC / WC / 16;
-  const int fr = lane & 15;
-  const int fq = lane >> 4;
-  const bool vec_ok = (p.N & 3) == 0;
-  // per-channel epilogue parameters of this lane's channels, loaded ONCE (they do not depend on the pixel):
-  // identity where absent, so the pixel loop below is branch-free in them
-  constexpr bool HOIST = CI <= 4;
-  f32x4_t hsc[HOIST ? CI : 1], hsh[HOIST ? CI : 1];
-  if (HOIST && vec_ok) {
-#pragma unroll
-    for (int c = 0; c < CI; ++c) {
-      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
-      hsc[c] = f32x4_t{1.f, 1.f, 1.f, 1.f};
-      hsh[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (n < p.N) {
-        if (p.ch_scale) hsc[c] = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
-        if (p.ch_shift) hsh[c] = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < PI; ++q) {
-    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
-    if (m >= p.M) continue;
-    int drow = m, sg = 0;
-#pragma unroll
-    for (int s = 0; s < kMaxSeg; ++s) {
-      if (s < p.nseg && m >= p.seg[s].m_begin) {
-        drow = p.seg[s].dst_row0 + (m - p.seg[s].m_begin);
-        sg = s;
-      }
-    }
-    float sscale = 1.f;
-    if (p.seg_scale) sscale = p.seg_scale[sg];
-#pragma unroll
-    for (int c = 0; c < CI; ++c) {
-      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]};
-      const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
-      if (vec_ok) {
-        if (HOIST) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * hsc[c][r] + hsh[c][r];
-        } else {
-          if (p.ch_scale) {
-            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_scale + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= s4[r];
-          }
-          if (p.ch_shift) {
-            const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ch_shift + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += s4[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] *= sscale;
-          if (p.act == KD6D_ACT_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
-          else if (p.act == KD6D_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.residual) {
-          if (p.out_f32) {
-            const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(
-                reinterpret_cast<const float*>(p.residual) + o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += r4[r];
-          } else {
-            const T* rp = reinterpret_cast<const T*>(p.residual) + o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
-          }
-        }
-        if (p.stats) acc[c][q] = f32x4_t{v[0], v[1], v[2], v[3]};
-        if (p.out_f32) {
-          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
-              f32x4_t{v[0], v[1], v[2], v[3]};
-        } else if (sizeof(T) == 4) {
-          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
-              f32x4_t{v[0], v[1], v[2], v[3]};
-        } else {
-          u32x2_t pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= p.N) continue;
-          float t = v[r];
-          if (p.ch_scale) t *= p.ch_scale[n + r];
-          if (p.ch_shift) t += p.ch_shift[n + r];
-          t *= sscale;
-          if (p.act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
-          else if (p.act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
-          if (p.residual) {
-            t += p.out_f32 ? reinterpret_cast<const float*>(p.residual)[o + r]
-                           : to_f32<T>(reinterpret_cast<const T*>(p.residual)[o + r]);
-          }
-          if (p.out_f32) reinterpret_cast<float*>(p.dst)[o + r] = t;
-          else reinterpret_cast<T*>(p.dst)[o + r] = from_f32<T>(t);
-        }
-      }
-    }
-  }
-  if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
-}
 
 template <typename T, int BP, int BC, int WP, int WC, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -570,16 +189,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // an LDS-DMA is linear).  Zero padding / tails fetch from a zero page.  One raw s_barrier per
 // k-step; loads are retired with counted s_waitcnt vmcnt so they stay in flight across barriers.
 // ---------------------------------------------------------------------------
-__device__ const uint4 kd6d_zero_page[4] = {};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p) {
@@ -820,187 +429,6 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvParams p
   }
 }
 
-// ---------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1, bf16, C % 64 == 0: "halo patch" implicit GEMM.
-//
-// The generic kernels fetch the im2col operand tap by tap, i.e. every input pixel 9 times, and
-// at these layer sizes they are bound by the ~28 B/clk a CU can pull from its XCD's L2, not by
-// MFMA.  Here a workgroup keeps the input pixels of its tile PLUS a halo (packed rows
-// [m0 - halo, m0 + BP + halo), halo = max level width + 1) resident in LDS for one 64-channel
-// chunk and builds all 9 taps from it: the pixel operand is fetched once instead of 9 times, so a
-// k-step streams only the weight tile (BC x 128 B).  The MFMA pixel fragment of tap (dy,dx) is a
-// plain ds_read_b128 at patch row (m - patch_lo) + dy*W + dx; out-of-image taps read a zero row.
-// k order is (chunk, tap, ci) instead of (tap, ci): only the fp32 summation order changes.
-// Everything travels by LDS-DMA: weights through a 3-deep ring (BC/8/waves instructions per wave
-// and k-step), the next chunk's patch double-buffered behind the current one; counted vmcnt,
-// one raw s_barrier per k-step.  Levels of a multi-level (head) launch may share a tile.
-// ---------------------------------------------------------------------------
-template <int BP, int BC, int WP, int WC, int MODE>
-__device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int total_rows, int bid, int nwg) {
-  using T = bf16_t;
-  constexpr int NW = WP * WC;
-  constexpr int PI = BP / WP / 16;
-  constexpr int CI = BC / WC / 16;
-  constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;   // 8-row groups of a patch (+1: the zero row lives in the last)
-  constexpr int PL = (PSLOT + NW - 1) / NW;          // patch LDS-DMA instructions per wave per chunk
-  constexpr int PATCH_BYTES = PL * NW * 1024;
-  constexpr int ZERO_ROW = PL * NW * 8 - 1;          // never a real patch row: always filled from the zero page
-  constexpr int WL = BC / 8 / NW;                    // weight LDS-DMA instructions per wave per k-step
-  constexpr int WSTAGE = BC * 128;
-  static_assert(BC % (8 * NW) == 0 && PI >= 1 && CI >= 1, "tile shape");
-  static_assert(WL + PL <= 63, "vmcnt range");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const pbuf = smem;                       // 2 patch buffers
-  char* const wring = smem + 2 * PATCH_BYTES;    // 3 weight stages
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wp = wave % WP;
-  const int wc = wave / WP;
-
-  const int wg = xcd_remap(bid, nwg);
-  const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
-  const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
-  const int m0 = tile_p * BP;
-  const int n0 = tile_c * BC;
-  const int patch_lo = m0 - halo;
-
-  const int lrow = lane >> 3;
-  const int gk = (lane & 7) ^ lrow;
-  const int fr = lane & 15;
-  const int fq = lane >> 4;
-
-  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
-  const char* zero = reinterpret_cast<const char*>(kd6d_zero_page);
-
-  // ---- per-lane pixel fragments: patch row of the centre tap, level width, 9-bit tap validity ----
-  int pbase[PI], pw[PI], pmask[PI];
-#pragma unroll
-  for (int q = 0; q < PI; ++q) {
-    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
-    const RowInfo ri = decode_row(p, m);      // packed identically on both sides: src row == dst row == m
-    pbase[q] = m - patch_lo;
-    pw[q] = ri.src_w;
-    // tap t = 3*ty + tx reads (y + dy, x + dx): three column bits, replicated into the valid rows
-    const int lo_x = ri.x > 0 ? 1 : 0, hi_x = ri.x + 1 < ri.src_w ? 1 : 0;
-    const int lo_y = ri.y > 0 ? 1 : 0, hi_y = ri.y + 1 < ri.src_h ? 1 : 0;
-    const int cols = MODE == MODE_FWD ? (lo_x | 2 | (hi_x << 2)) : (hi_x | 2 | (lo_x << 2));
-    const int r0 = MODE == MODE_FWD ? lo_y : hi_y, r2 = MODE == MODE_FWD ? hi_y : lo_y;
-    const int mask = (r0 ? cols : 0) | (cols << 3) | (r2 ? (cols << 6) : 0);
-    pmask[q] = m < p.M ? mask : 0;
-  }
-
-  // ---- loaders ----
-  int wofs[WL];
-#pragma unroll
-  for (int i = 0; i < WL; ++i) {
-    const int n = n0 + 8 * (wave + NW * i) + lrow;
-    wofs[i] = n < p.N ? n * p.K + gk * 8 : -1;
-  }
-  auto issue_w = [&](int stage, int chunk, int tap) {
-    char* base = wring + stage * WSTAGE + wave * 1024;
-    const int kk0 = tap * p.C + chunk * 64;
-#pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const void* g = zero;
-      if (wofs[i] >= 0) g = wgt + ((size_t)wofs[i] + (size_t)kk0);
-      glds16(g, base + i * NW * 1024);
-    }
-  };
-  auto issue_patch = [&](int buf, int chunk) {
-    char* base = pbuf + buf * PATCH_BYTES + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int slot = wave + NW * i;
-      const int prow = 8 * slot + lrow;
-      const int row = patch_lo + prow;
-      const void* g = zero;
-      if (prow < BP + 2 * halo && row >= 0 && row < total_rows)
-        g = src + ((size_t)row * (size_t)p.C + (size_t)(chunk * 64 + gk * 8));
-      glds16(g, base + i * NW * 1024);
-    }
-  };
-
-  f32x4_t acc[CI][PI];
-#pragma unroll
-  for (int c = 0; c < CI; ++c)
-#pragma unroll
-    for (int q = 0; q < PI; ++q) acc[c][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nchunk = p.C >> 6;
-  const int nk = nchunk * 9;
-
-  // prologue: queue = [PATCH(0), W(0), W(1)]
-  issue_patch(0, 0);
-  issue_w(0, 0, 0);
-  issue_w(1, 0, 1);
-  int wstage = 0;              // ring slot of W(kt)
-  int c2 = 0, t2 = 2;          // (chunk, tap) of W(kt+2)
-
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const bool more_patch = chunk + 1 < nchunk;
-    const char* patch = pbuf + (chunk & 1) * PATCH_BYTES;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kt = chunk * 9 + tap;
-      // retire W(kt); W(kt+1) and (taps 1,2) the next chunk's patch stay in flight
-      if (kt + 1 >= nk) wait_vmcnt<0>();
-      else if ((tap == 1 || tap == 2) && more_patch) wait_vmcnt<WL + PL>();
-      else wait_vmcnt<WL>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk) {
-        int st2 = wstage + 2;
-        if (st2 >= 3) st2 -= 3;
-        issue_w(st2, c2, t2);
-        if (++t2 == 9) { t2 = 0; ++c2; }
-      }
-      if (tap == 0 && more_patch) issue_patch((chunk + 1) & 1, chunk + 1);
-
-      const char* wt = wring + wstage * WSTAGE;
-      const int dy = MODE == MODE_FWD ? tap / 3 - 1 : 1 - tap / 3;
-      const int dx = MODE == MODE_FWD ? tap % 3 - 1 : 1 - tap % 3;
-      int nrow[PI];
-#pragma unroll
-      for (int q = 0; q < PI; ++q) {
-        const int r = pbase[q] + dy * pw[q] + dx;
-        nrow[q] = ((pmask[q] >> tap) & 1) ? r : ZERO_ROW;
-      }
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {
-        Frag<T> fa[CI], fb[PI];
-#pragma unroll
-        for (int c = 0; c < CI; ++c) load_frag<T>(wt, wc * (BC / WC) + c * 16 + fr, ch, fq, fa[c]);
-#pragma unroll
-        for (int q = 0; q < PI; ++q) load_frag<T>(patch, nrow[q], ch, fq, fb[q]);
-#pragma unroll
-        for (int c = 0; c < CI; ++c)
-#pragma unroll
-          for (int q = 0; q < PI; ++q) mma(fa[c], fb[q], acc[c][q]);
-      }
-      if (++wstage == 3) wstage = 0;
-    }
-  }
-  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
-}
-
-template <int BP, int BC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
-  halo_tile<BP, BC, WP, WC, MODE>(p, halo, total_rows, blockIdx.x, gridDim.x);
-}
-
-// Two convolutions of identical geometry (the cls and the pose tower layer of the head: different tensors and
-// weights, same shapes) as ONE launch: workgroups [0, tiles_a) run `pa`, the rest `pb`.  A student tower layer
-// alone is 170 tiles of 128x128 on 256 CUs, one 128-KB workgroup per CU -- a second stream cannot use the idle
-// third; as a pair the two layers are 228 tiles of 192x128, one full round for both.
-template <int BP, int BC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_pair_kernel(const ConvParams pa, const ConvParams pb,
-                                                                        int halo, int total_rows, int tiles_a) {
-  if ((int)blockIdx.x < tiles_a) halo_tile<BP, BC, WP, WC, MODE>(pa, halo, total_rows, blockIdx.x, tiles_a);
-  else halo_tile<BP, BC, WP, WC, MODE>(pb, halo, total_rows, blockIdx.x - tiles_a, gridDim.x - tiles_a);
-}
 
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1, bf16, C in {8, 16, 32}: the wide, shallow layers at the top of both
@@ -1731,78 +1159,6 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ w
   }
 }
 
-// ---------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------
-bool fill_segs(const kd6d_conv_geom* g, bool dgrad, SegDev* seg, int* M_out) {
-  int m = 0;
-  for (int s = 0; s < g->nseg; ++s) {
-    const kd6d_seg& gs = g->seg[s];
-    SegDev& d = seg[s];
-    if (!dgrad) {
-      d.src_h = gs.in_h; d.src_w = gs.in_w; d.dst_h = gs.out_h; d.dst_w = gs.out_w;
-      d.src_row0 = gs.in_row0; d.dst_row0 = gs.out_row0;
-    } else {
-      d.src_h = gs.out_h; d.src_w = gs.out_w; d.dst_h = gs.in_h; d.dst_w = gs.in_w;
-      d.src_row0 = gs.out_row0; d.dst_row0 = gs.in_row0;
-    }
-    d.dst_hw = d.dst_h * d.dst_w;
-    d.inv_hw = 1.0f / (float)d.dst_hw;
-    d.inv_w = 1.0f / (float)d.dst_w;
-    d.m_begin = m;
-    if (d.src_h > 32767 || d.src_w > 32767 || d.src_h < 0 || d.src_w < 0) return false;
-    if ((long long)m + (long long)g->batch * d.dst_hw >= (1ll << 24)) return false;   // fast_div range
-    m += g->batch * d.dst_hw;
-  }
-  *M_out = m;
-  return true;
-}
-
-int check_geom(const kd6d_conv_geom* g, int dtype, const char* who) {
-  KD6D_CHECK_ARG(g != nullptr, "%s: null geometry", who);
-  KD6D_CHECK_ARG(g->nseg >= 1 && g->nseg <= kMaxSeg, "%s: nseg=%d out of range", who, g->nseg);
-  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "%s: bad dtype %d", who, dtype);
-  const int eg = dtype == KD6D_BF16 ? 8 : 4;
-  KD6D_CHECK_ARG(g->cin > 0 && g->cin % eg == 0, "%s: cin=%d must be a multiple of %d", who, g->cin, eg);
-  KD6D_CHECK_ARG(g->cout > 0, "%s: cout=%d", who, g->cout);
-  KD6D_CHECK_ARG(g->ksize >= 1 && g->ksize <= 7 && g->stride >= 1 && g->stride <= 4 && g->pad >= 0,
-                 "%s: bad ksize/stride/pad %d/%d/%d", who, g->ksize, g->stride, g->pad);
-  KD6D_CHECK_ARG(g->batch >= 1, "%s: batch=%d", who, g->batch);
-  for (int s = 0; s < g->nseg; ++s) {
-    const kd6d_seg& q = g->seg[s];
-    KD6D_CHECK_ARG(q.in_h > 0 && q.in_w > 0 && q.out_h > 0 && q.out_w > 0, "%s: empty level %d", who, s);
-    KD6D_CHECK_ARG(q.out_h == (q.in_h + 2 * g->pad - g->ksize) / g->stride + 1 &&
-                       q.out_w == (q.in_w + 2 * g->pad - g->ksize) / g->stride + 1,
-                   "%s: level %d output grid %dx%d inconsistent with input %dx%d", who, s, q.out_h,
-                   q.out_w, q.in_h, q.in_w);
-  }
-  return KD6D_OK;
-}
-
-// Workgroup order.  After the XCD remap an XCD runs a CONTIGUOUS range of ~1/8 of the tile ids, so the
-// fastest-varying tile index decides which operand that XCD's 4 MiB L2 can keep: channel tiles fastest
-// -> the XCD touches few pixel tiles but ALL weights; pixel tiles fastest -> few weight tiles but many
-// pixels.  Pick the order with the smaller per-XCD footprint (small-M / wide-N layers: weights).
-void set_tile_order(ConvParams& q, int ptiles, int BP, int BC) {
-  q.n_ptiles = ptiles;
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_ORDER");
-    return e ? atoi(e) : -1;
-  }();
-  const double tiles = (double)ptiles * q.n_ctiles;
-  const double per_xcd = tiles / 8.0;
-  const double w_tile = (double)BC * q.K * 2.0, x_tile = (double)BP * q.C * 2.0 * (q.ks > 1 ? 1.5 : 1.0);
-  // channel tiles fastest: an XCD spans per_xcd / n_ctiles pixel tiles (>= 1) and min(per_xcd, n_ctiles) weight tiles
-  auto foot = [&](double n_fast, double t_fast, double t_slow) {
-    const double fast = per_xcd < n_fast ? per_xcd : n_fast;
-    const double slow = per_xcd / n_fast < 1.0 ? 1.0 : per_xcd / n_fast;
-    return fast * t_fast + slow * t_slow;
-  };
-  const double c_fast = foot(q.n_ctiles, w_tile, x_tile);
-  const double p_fast = foot(ptiles, x_tile, w_tile);
-  q.p_fastest = p_fast < c_fast ? 1 : 0;
-  if (force >= 0) q.p_fastest = force;
-}
 
 template <typename T, int BP, int BC, int WP, int WC, int MODE>
 void launch_igemm(const ConvParams& p, hipStream_t st) {
@@ -1838,133 +1194,7 @@ void launch_glds(const ConvParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q);
 }
 
-int cached_cu_count() {       // one device per process
-  static const int n = []() { const int c = kd6d_device_cu_count(); return c > 0 ? c : 256; }();
-  return n;
-}
 
-// kd6d_conv2d_pair_begin / _end: between the two calls, halo-kernel launches are recorded instead of issued; two
-// recorded launches of the same kernel variant and geometry go out as one conv3x3_halo_pair_kernel launch.
-struct HaloRecord {
-  ConvParams q;
-  int halo, total_rows, tiles;
-  hipStream_t st;
-  void (*single)(const HaloRecord&);
-  void (*pair)(const HaloRecord&, const HaloRecord&);
-};
-struct PairState {
-  bool active = false;
-  int count = 0;
-  HaloRecord rec[2];
-};
-thread_local PairState g_pair;
-
-template <int BP, int BC, int WP, int WC, int MODE>
-size_t halo_lds() {
-  constexpr int NW = WP * WC;
-  constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;
-  constexpr int PL = (PSLOT + NW - 1) / NW;
-  return (size_t)2 * PL * NW * 1024 + (size_t)3 * BC * 128;
-}
-
-template <int BP, int BC, int WP, int WC, int MODE>
-void halo_issue_single(const HaloRecord& r) {
-  const size_t lds = halo_lds<BP, BC, WP, WC, MODE>();
-  auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(r.tiles), dim3(WP * WC * 64), lds, r.st, r.q, r.halo, r.total_rows);
-}
-
-template <int BP, int BC, int WP, int WC, int MODE>
-void halo_issue_pair(const HaloRecord& a, const HaloRecord& b) {
-  const size_t lds = halo_lds<BP, BC, WP, WC, MODE>();
-  auto kern = conv3x3_halo_pair_kernel<BP, BC, WP, WC, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(a.tiles + b.tiles), dim3(WP * WC * 64), lds, a.st, a.q, b.q, a.halo, a.total_rows,
-                     a.tiles);
-}
-
-template <int BP, int BC, int WP, int WC, int MODE>
-void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
-  HaloRecord r;
-  r.q = p;
-  r.q.n_ctiles = (p.N + BC - 1) / BC;
-  const int ptiles = (p.M + BP - 1) / BP;
-  set_tile_order(r.q, ptiles, BP, BC);
-  r.halo = halo; r.total_rows = total_rows; r.tiles = ptiles * r.q.n_ctiles; r.st = st;
-  r.single = &halo_issue_single<BP, BC, WP, WC, MODE>;
-  r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE>;
-  if (g_pair.active && g_pair.count < 2) { g_pair.rec[g_pair.count++] = r; return; }
-  r.single(r);
-}
-
-// 3x3/s1/p1 layers with C % 64 == 0 on maps at most 64 wide, both sides packed identically.
-template <int MODE>
-bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128, 2 = 128x128 (4 waves), 3 = 128x128, 4 = 128x64,
-                                                // 5 = 128x32, 6 = 192x128, 9 = 64x64
-    return e ? atoi(e) : -1;
-  }();
-  if (force == 0) return false;
-  static const int narrow = []() { const char* e = getenv("KD6D_CONV_HALO_NARROW"); return e ? atoi(e) : 1; }();
-  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C & 63) || (p.N & 3)) return false;
-  if (p.N < 64 && (!narrow || p.N > 32)) return false;
-  int wmax = 0, rows = 0;
-  for (int s = 0; s < g->nseg; ++s) {
-    const kd6d_seg& q = g->seg[s];
-    if (q.in_row0 != q.out_row0 || q.in_row0 != rows) return false;
-    if (q.in_w > wmax) wmax = q.in_w;
-    rows += g->batch * q.in_h * q.in_w;
-  }
-  if (wmax > 64) return false;
-  const int halo = wmax + 1;
-  // measured on the step's layers (tools/bench_conv.py), all variants with 8 waves (2 per SIMD: with 4 waves
-  // the same 128x128 tile is 25-40 % slower, one wave per SIMD cannot hide the LDS-DMA / fragment latency):
-  //   256x128 once it yields >= 150 workgroups (teacher head, stage 2);
-  //   128x128 from >= 160 workgroups (teacher stage 3, FPN 32x32 level, student head towers fwd + dgrad);
-  //   128x64  from >= 64 workgroups (teacher stage 4, student FPN 32x32 level) -- ahead of split-K;
-  //   192x128 / 64x64 / 128x32: the tile-count corner cases below;
-  // below that the layer goes to split-K / the generic kernels.
-  // inside a kd6d_conv2d_pair_begin/_end bracket the launch shares the device with its twin: count tiles twice
-  const int pf = g_pair.active ? 2 : 1;
-  const int pt128 = pf * ((p.M + 127) / 128);
-  int pick = 0;
-  const int ct128 = (p.N + 127) / 128;
-  const int ncu = cached_cu_count();
-  const int ct64 = (p.N + 63) / 64;
-  // few result channels (cls logits, dgrad into the narrow student stages): 128 x 32, or 64 x 64 on small maps
-  if (p.N <= 32) pick = pt128 <= ncu / 2 ? 9 : 5;
-  // 128 x 64 tiles would occupy at most half of the CUs: 64 x 64 (FPN 16x16 level, stage 5, student FPN)
-  else if (pt128 * ct64 <= ncu / 2 && pf * ((p.M + 63) / 64) * ct64 >= 64) pick = 9;
-  // 192 x 128 where it turns 256-pixel tiles that leave a third of the CUs idle into one full round (teacher head
-  // towers: 172 tiles of 256 pixels on 256 CUs -> 228 tiles of 192)
-  else if (pf * ((p.M + 255) / 256) * ct128 >= 150 && pf * ((p.M + 255) / 256) * ct128 <= (3 * ncu) / 4 &&
-           pf * ((p.M + 191) / 192) * ct128 <= ncu) pick = 6;
-  else if (pf * ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
-  else if (pt128 * ((p.N + 127) / 128) >= 160) pick = 3;
-  else if (pt128 * ((p.N + 63) / 64) >= 64) pick = 4;
-  if (force > 0) pick = force;
-  if (pick == 0) return false;
-  if (pick == 1) launch_halo<256, 128, 4, 2, MODE>(p, halo, rows, st);
-  else if (pick == 3) launch_halo<128, 128, 4, 2, MODE>(p, halo, rows, st);      // 8 waves on the 128x128 tile
-  else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);
-  else if (pick == 5) launch_halo<128, 32, 4, 1, MODE>(p, halo, rows, st);
-  else if (pick == 6) launch_halo<192, 128, 4, 2, MODE>(p, halo, rows, st);
-  else if (pick == 9) launch_halo<64, 64, 4, 2, MODE>(p, halo, rows, st);
-  else launch_halo<128, 128, 2, 2, MODE>(p, halo, rows, st);
-  return true;
-}
 
 template <int CG, int NB, int MODE>
 void launch_smallc(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
@@ -2271,31 +1501,6 @@ void dispatch_wgrad(const WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int kd6d_conv2d_pair_begin(void) {
-  KD6D_CHECK_ARG(!g_pair.active, "kd6d_conv2d_pair_begin: already inside a pair bracket");
-  g_pair.active = true;
-  g_pair.count = 0;
-  return KD6D_OK;
-}
-
-extern "C" int kd6d_conv2d_pair_pending(void) { return g_pair.active ? g_pair.count : 0; }
-
-extern "C" int kd6d_conv2d_pair_end(void) {
-  KD6D_CHECK_ARG(g_pair.active, "kd6d_conv2d_pair_end: no pair bracket open");
-  g_pair.active = false;
-  const int n = g_pair.count;
-  g_pair.count = 0;
-  const HaloRecord& a = g_pair.rec[0];
-  const HaloRecord& b = g_pair.rec[1];
-  if (n == 2 && a.pair == b.pair && a.halo == b.halo && a.total_rows == b.total_rows && a.st == b.st) {
-    a.pair(a, b);
-  } else {
-    for (int i = 0; i < n; ++i) g_pair.rec[i].single(g_pair.rec[i]);
-  }
-  KD6D_CHECK_LAUNCH("kd6d_conv2d_pair_end");
-  return KD6D_OK;
-}
-
 extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
                                void* y, const float* ch_scale, const float* ch_shift, int act,
                                const void* residual, const float* seg_scale, int out_f32,
@@ -2325,7 +1530,7 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    if (!dispatch_smallc<MODE_FWD>(p, g, st) && !dispatch_halo<MODE_FWD>(p, g, st) &&
+    if (!dispatch_smallc<MODE_FWD>(p, g, st) && !dispatch_halo_fwd(p, g, st) &&
         !dispatch_splitk<MODE_FWD>(p, reinterpret_cast<float*>(workspace), (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), st) &&
         !dispatch_glds<MODE_FWD>(p, st))
       dispatch_igemm<bf16_t, MODE_FWD>(p, st);
@@ -2354,7 +1559,7 @@ extern "C" int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void*
   p.act = KD6D_ACT_NONE; p.out_f32 = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) {
-    if (!dispatch_smallc<MODE_DGRAD>(p, g, st) && !dispatch_halo<MODE_DGRAD>(p, g, st) && !dispatch_glds<MODE_DGRAD>(p, st))
+    if (!dispatch_smallc<MODE_DGRAD>(p, g, st) && !dispatch_halo_dgrad(p, g, st) && !dispatch_glds<MODE_DGRAD>(p, st))
       dispatch_igemm<bf16_t, MODE_DGRAD>(p, st);
   } else {
     dispatch_igemm<float, MODE_DGRAD>(p, st);
