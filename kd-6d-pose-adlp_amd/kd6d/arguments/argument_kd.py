@@ -63,6 +63,9 @@ def get_argparser():
     p.add_argument("--batch_size", type=int, default=0, help="global batch; 0 = SOLVER.IMS_PER_BATCH")
     p.add_argument("--image_size", type=int, default=256, help="synthetic crop size")
     p.add_argument("--val_freq", type=int, default=0, help="validate every N steps; 0 = the backbone's default")
+    p.add_argument("--teacher_pnp_gate", action="store_true",
+                   help="keep a teacher's cells only if RANSAC-PnP solves a pose from them (postprocess_kd.py:187-202); "
+                        "needs --launch eager (one host synchronisation per step)")
     p.add_argument("--mixed_classes", type=str2bool, nargs="?", const=True, default=None,
                    help="synthetic batches mix the 13 LINEMOD classes (default: DATASETS.MIXED_CLASSES of the yaml)")
     return p
@@ -90,7 +93,8 @@ def load_yaml(path):
 
 def _runtime(args, config_file, weight_file):
     return dict(LOCAL_RANK=args.local_rank, CONFIG_FILE=config_file, NUM_WORKERS=args.num_workers,
-                WEIGHT_FILE=weight_file, RUNNING_DEVICE=args.running_device, PRECISION=args.precision)
+                WEIGHT_FILE=weight_file, RUNNING_DEVICE=args.running_device, PRECISION=args.precision,
+                TEACHER_PNP_GATE=bool(args.teacher_pnp_gate))
 
 
 def build_cfgs(args):

@@ -39,9 +39,18 @@ def valid(cfg, steps, loader, model, device, meshes, logger=None):
     ms = [m if hasattr(m, "vertices") else _Mesh(m) for m in meshes]
     out = evaluate_pose_predictions(preds, cfg["DATASETS"]["N_CLASS"], ms, cfg["DATASETS"]["MESH_DIAMETERS"],
                                     cfg["DATASETS"].get("SYMMETRY_TYPES", {}))
-    if logger is not None:
+    if logger is not None:            # eval_libs.py:112-146 of the reference: per class, then the mean over classes seen
+        all_adi, all_rep, n_valid = {}, {}, 0
         for i, (adi, rep) in enumerate(zip(out[0], out[2])):
             if adi:
                 logger.add_scalars("ADI/class_%02d" % i, adi, steps)
                 logger.add_scalars("REP/class_%02d" % i, rep, steps)
+                for k, v in adi.items():
+                    all_adi[k] = all_adi.get(k, 0.0) + v
+                for k, v in rep.items():
+                    all_rep[k] = all_rep.get(k, 0.0) + v
+                n_valid += 1
+        if n_valid:
+            logger.add_scalars("ADI/all_class", {k: v / n_valid for k, v in all_adi.items()}, steps)
+            logger.add_scalars("REP/all_class", {k: v / n_valid for k, v in all_rep.items()}, steps)
     return out

@@ -9,6 +9,7 @@ same before being discarded) and gradients are mean-all-reduced every step over 
 """
 import os
 
+import numpy as np
 import torch
 from torch import optim
 
@@ -58,12 +59,15 @@ def build_model(cfg, posemodule, device="cuda"):
     wd = cfg["RUNTIME"].get("WORKING_DIR", "")
     latest = os.path.join(wd, "latest.pth") if wd else ""
     if latest and os.path.exists(latest):
-        chkpt = torch.load(latest, map_location="cpu")
+        chkpt = torch.load(latest, map_location="cpu", weights_only=False)
         total_steps = chkpt["steps"]
         model.load_state_dict(chkpt["model"])
-        optimizer.load_state_dict(chkpt["optim"])
-        scheduler.load_state_dict(chkpt["sched"])
-        print("Weights, optimzer, scheduler are loaded from %s, starting from step %d" % (latest, total_steps))
+        try:
+            optimizer.load_state_dict(chkpt["optim"])
+            scheduler.load_state_dict(chkpt["sched"])
+            print("Weights, optimzer, scheduler are loaded from %s, starting from step %d" % (latest, total_steps))
+        except ValueError as e:      # e.g. an `optim` entry written by the reference's torch.optim.AdamW
+            print("Weights are loaded from %s; optimiser / scheduler state NOT resumed: %s" % (latest, e))
     return model, optimizer, scheduler, total_steps
 
 
@@ -76,3 +80,81 @@ def build_model_teacher(cfg, posemodule, device):
         D.broadcast_(model.net.store.bufs, 0)
         model.net.invalidate()
     return model
+
+
+class DziLoader:
+    """DataLoader of full frames -> what the reference's loaders yield after `dzi_train` / `dzi_test`
+    (libs/dzi_libs.py:55-140) and `collate_fn`: (ImageList of 256x256 normalised crops, targets with the cropped mask,
+    bbox_trans and bbox_scale, meta_infos).  Normalize + the affine crop of image and mask run as ONE kd6d_dzi_crop
+    launch per batch on the GPU; the three jitter numbers per image come from numpy's global RNG like the reference.
+    The CPU augmentation chain of libs/transform.py is not rebuilt: frames must already have the internal resolution."""
+
+    def __init__(self, loader, cfg, device, training):
+        from .dzi_libs import normalize_lut
+        self.loader, self.cfg, self.device, self.training = loader, cfg, device, training
+        self.lut = normalize_lut(cfg["INPUT"]["PIXEL_MEAN"], cfg["INPUT"]["PIXEL_STD"], device)
+        self.size = (cfg["INPUT"]["INTERNAL_HEIGHT"], cfg["INPUT"]["INTERNAL_WIDTH"])
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        from ..kd_losses import PackedTargets
+        from .dataset import projected_box
+        from .dzi_libs import aug_bbox_DZI, dzi_batch, test_bbox_DZI
+        from .poses import ImageList, PoseAnnot
+        for frames, masks, targets, metas in self.loader:
+            B, H, W, _ = frames.shape
+            if (H, W) != tuple(self.size):
+                raise ValueError("frames are %dx%d but INPUT.INTERNAL_* is %dx%d: the CPU Resize transform of the reference "
+                                 "is not rebuilt, store the frames at the internal resolution" % (W, H, self.size[1], self.size[0]))
+            centers, scales = [], []
+            for t in targets:
+                box = projected_box(t, 0)                                   # to_object_boxlist().bbox[0]
+                c, s = aug_bbox_DZI(box, H, W) if self.training else test_bbox_DZI(box, H, W)
+                centers.append(c); scales.append(s)
+            images, crop_masks, trans, bscale = dzi_batch(frames.to(self.device, non_blocking=True).contiguous(),
+                                                          masks.to(self.device, non_blocking=True).contiguous(),
+                                                          np.stack(centers), np.asarray(scales), self.lut)
+            R = images.shape[-1]
+            dev = self.device
+            out = [PoseAnnot(t.keypoints_3d.to(dev), t.K.to(dev), crop_masks[i], t.class_ids.to(dev), t.rotations.to(dev),
+                             t.translations.to(dev), R, R, bscale[i], trans[i]) for i, t in enumerate(targets)]
+            yield ImageList(images, [(R, R)] * B), PackedTargets(out, dev), metas
+
+
+def build_dataset(cfg, device="cuda"):
+    """libs/train_libs.py:209-291: (train_loader, valid_loader) over the BOP image lists of cfg['DATASETS'], batch
+    = IMS_PER_BATCH / N_GPU per rank, DistributedSampler semantics of libs/distributed.py.  DATASETS.TRAIN may be one
+    list file or several (configs/linemod13.yaml): the datasets are concatenated."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    from .dataset import BOP_Dataset, collate_frames
+    ds = cfg["DATASETS"]
+
+    def make(files, training):
+        files = [files] if isinstance(files, str) else list(files)
+        sets = [BOP_Dataset(f, ds["MESH_DIR"], ds["BBOX_FILE"], ds.get("SYMMETRY_TYPES"), training=training) for f in files]
+        return sets[0] if len(sets) == 1 else ConcatDataset(sets)
+
+    train_set, valid_set = make(ds["TRAIN"], True), make(ds["VALID"], False)
+    per_gpu = D.shard_batch(cfg["SOLVER"]["IMS_PER_BATCH"])
+    dist_on = cfg["RUNTIME"].get("DISTRIBUTED", False)
+
+    def loader(dset, shuffle):
+        if dist_on:
+            smp = D.DistributedSampler(dset, shuffle=shuffle)
+        elif shuffle:
+            smp = torch.utils.data.RandomSampler(dset)
+        else:
+            smp = torch.utils.data.SequentialSampler(dset)
+        return DataLoader(dset, batch_size=per_gpu, sampler=smp, num_workers=cfg["RUNTIME"].get("NUM_WORKERS", 0),
+                          collate_fn=collate_frames, drop_last=shuffle)
+
+    return DziLoader(loader(train_set, True), cfg, device, True), DziLoader(loader(valid_set, False), cfg, device, False)
+
+
+def dataset_meshes(loader):
+    """Mesh vertex arrays per class id of a DziLoader's dataset (what valid() measures ADI / REP on)."""
+    dset = loader.loader.dataset
+    dset = dset.datasets[0] if hasattr(dset, "datasets") else dset
+    return [m.vertices for m in dset.meshes]

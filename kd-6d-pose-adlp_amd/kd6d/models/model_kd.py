@@ -69,6 +69,11 @@ class PoseModuleKD(nn.Module):
         kd = cfg.get("KD", {})
         if "LEVEL" in kd and kd["LEVEL"] != "pred":
             raise KeyError("Ooops, KD from %s is not defined." % kd["LEVEL"])
+        # postprocess_kd.py:187-202: the reference runs RANSAC-EPnP on a teacher's selected cells and keeps the image's
+        # cells only if the solver succeeds.  Off by default (it needs the cells on the host: one synchronisation per
+        # step, which a replayed hipGraph cannot contain); cfg['RUNTIME']['TEACHER_PNP_GATE'] (--teacher_pnp_gate) turns
+        # it on for eager launches, with kd6d/libs/pnp.py as the solver
+        self.teacher_pnp_gate = bool(cfg.get("RUNTIME", {}).get("TEACHER_PNP_GATE", False))
         self.loss_evaluator = KDLoss(cfg["INPUT"]["INTERNAL_K"], cfg["DATASETS"]["MESH_DIAMETERS"],
                                      cfg["SOLVER"]["FOCAL_GAMMA"], cfg["SOLVER"]["FOCAL_ALPHA"], self.positive_num,
                                      self.positive_lambda, kd if "GTYPE" in kd else None)
@@ -184,13 +189,41 @@ class PoseModuleKD(nn.Module):
         if is_teacher:
             cls, reg = net.forward(x)
             tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
-            return kd_losses.teacher_select(cls, reg, net.levels, B, tgt.bbox_trans, self.inference_th,
-                                            self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh,
-                                            flats=getattr(self, "_teacher_flats", None))
+            tk = kd_losses.teacher_select(cls, reg, net.levels, B, tgt.bbox_trans, self.inference_th,
+                                          self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh,
+                                          flats=getattr(self, "_teacher_flats", None))
+            if self.teacher_pnp_gate:
+                self._apply_pnp_gate(tk, cls, tgt)
+            return tk
         # evaluation: candidate cells per ground-truth class on the GPU, PnP-RANSAC on the host (models/model_kd.py:94-95)
         cls, reg = net.forward(x)
         tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
         return self.post_processor(cls, reg, net.levels, B, tgt), {}
+
+    def _apply_pnp_gate(self, tk, cls, tgt):
+        """Drop the teacher cells of every image whose pose cannot be solved from them (postprocess_kd.py:187-202).
+        Host round trip: eager launches only."""
+        import numpy as np
+        from ..libs.pnp import solve_pnp_ransac
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the teacher PnP gate synchronises with the host: use --launch eager with it")
+        cnt = tk.t_cnt.cpu().tolist()
+        kp = tk.t_kp.cpu().numpy()
+        rows = tk.t_row.cpu().numpy()
+        K, kp3d = tgt.K.cpu().numpy(), tgt.kp3d.cpu().numpy()
+        keep = []
+        for b, n in enumerate(cnt):
+            ok = False
+            if n > 0:
+                r0 = int(rows[b * tk.cap])
+                prob = torch.sigmoid(cls[r0, :self.net.n_cls]).cpu().numpy()
+                cand = np.nonzero(prob > self.inference_th)[0]
+                c = int(cand[0]) if len(cand) else int(prob.argmax())   # labels are visited in ascending order, first result kept
+                uv = kp[b * tk.cap:b * tk.cap + n].reshape(-1, 2)
+                xyz = np.tile(kp3d[b, c], (n, 1))
+                ok = solve_pnp_ransac(xyz, uv, K[b], reproj_err=5.0)[0]
+            keep.append(1 if ok else 0)
+        tk.t_cnt.mul_(torch.tensor(keep, dtype=tk.t_cnt.dtype, device=tk.t_cnt.device))
 
     def _forward_losses(self, x, targets, pred_t):
         """Student forward + the three loss sums -> fp32[3] device tensor {cls, reg, kd} (unweighted)."""

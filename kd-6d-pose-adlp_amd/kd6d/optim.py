@@ -66,6 +66,13 @@ class FusedClipAdamW(torch.optim.Optimizer):
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 
     def load_state_dict(self, sd):
+        if "steps" not in sd or "exp_avg" not in sd:
+            # a torch.optim.AdamW state dict ('state' per parameter index + 'param_groups'), e.g. the `optim` entry of a
+            # latest.pth the reference wrote: per-parameter moments in the reference's registration order do not map
+            # onto the flat buffers without the reference's module tree
+            raise ValueError("FusedClipAdamW.load_state_dict: this is not a kd6d optimiser state (keys %s); a "
+                             "torch.optim.AdamW state cannot be resumed here -- load only the 'model' entry of the "
+                             "checkpoint (Adam moments restart from zero)" % sorted(sd.keys()))
         self.steps = int(sd["steps"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -127,3 +127,45 @@ def test_onecycle_lr_trajectory_matches_reference_capture():
         lrs.append(opt.param_groups[0]["lr"])
         opt.step(); sch.step()
     np.testing.assert_allclose(lrs, z["lrs"], rtol=1e-12)
+
+
+def test_model_zoo_file_and_backbone_only_state_dict(tmp_path, monkeypatch):
+    """backbone/model_store.py:540-592 + libs/train_libs.py:82-87: `pretrained=True` resolves
+    `<root>/<name>-<error>-<sha1[:8]>.pth` in the local model store (no download), checks its SHA-1, and the
+    backbone-only state_dict (`features.*`, `output.*`) lands under `backbone.*` of the pose module, leaving FPN and
+    head at their initialisation."""
+    import hashlib
+    import warnings
+    import torch
+    from kd6d import backbone as BB
+    from kd6d.models.model_kd import PoseModuleKD
+    from oracle import kd_step_ref as O
+    assert BB.MODEL_STORE["darknet53"] == ("0564", "b36bef6b297055dda3d17a3f79596511730e1963")
+    assert BB.MODEL_STORE["darknet_tiny"][0] == "1784"
+    root = str(tmp_path)
+    zoo = O.DarkNetTinyRef("darknet_tiny")
+    sd = O.seeded_state_dict(zoo, 9)
+    tmp = os.path.join(root, "blob.pth")
+    torch.save(sd, tmp)
+    sha = hashlib.sha1(open(tmp, "rb").read()).hexdigest()
+    monkeypatch.setitem(BB.MODEL_STORE, "darknet_tiny", ("1784", sha))
+    os.rename(tmp, os.path.join(root, "darknet_tiny-1784-%s.pth" % sha[:8]))
+    spec = BB.darknet_tiny(pretrained=True, root=root)
+    assert spec.pretrained_file and spec.pretrained_file.endswith("darknet_tiny-1784-%s.pth" % sha[:8])
+    torch.manual_seed(0)
+    m = PoseModuleKD(_cfg("darknet_tiny"), spec)
+    got = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        assert torch.equal(got["backbone." + k], v), k
+    assert float(got["head.cls_logits.bias"][0]) == pytest.approx(-4.59512, abs=1e-4)      # untouched: prior init
+    # wrong content -> ignored with a warning; missing -> random init with a warning
+    monkeypatch.setitem(BB.MODEL_STORE, "darknet_tiny", ("1784", "0" * 40))
+    os.rename(os.path.join(root, "darknet_tiny-1784-%s.pth" % sha[:8]), os.path.join(root, "darknet_tiny-1784-00000000.pth"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert BB.darknet_tiny(pretrained=True, root=root).pretrained_file is None
+        assert BB.darknet53(pretrained=True, root=root).pretrained_file is None
+    assert any("Mismatch" in str(x.message) for x in w) and any("random init" in str(x.message) for x in w)
+    assert BB.darknet_tiny_h(pretrained=False).pretrained_file is None

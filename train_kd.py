@@ -6,10 +6,13 @@ train_kd.py:34-171, on the MI355X-native kd6d step.
         --kd_weight 5. --max_iters 10000 --working_dir outputs/ape/kd/ --synthetic
 
 Multi-GPU: python -m torch.distributed.run --nproc-per-node N train_kd.py ...  (one process per
-GPU, backend nccl = RCCL).  The BOP/LINEMOD reader of the reference is outside the hot path (SURVEY.md
-8(f)-4); without --synthetic this script stops with a clear message.  Every VAL_FREQ steps rank 0 runs the
-evaluation path (kd6d/libs/eval_libs.valid: eval forward -> pose candidates -> PnP-RANSAC -> ADI / REP) on
-held-out synthetic batches, the 3D-box corners standing in for the meshes.
+GPU; the gradient exchange goes through kd6d_comm_* = librccl over xGMI).  Without --synthetic the BOP / LINEMOD
+image lists of the yaml are read (kd6d/libs/train_libs.build_dataset: frames at the internal resolution, the
+Dynamic-Zoom-In crop + normalisation run on the GPU); with it, seeded LINEMOD-shaped batches.  As in the
+reference the teacher is validated once before training (skip with --skip_teacher_eval) and every VAL_FREQ steps
+rank 0 validates the student (kd6d/libs/eval_libs.valid: eval forward -> pose candidates -> PnP-RANSAC -> ADI /
+REP) and writes latest.pth.  Scalars go to tensorboardX under the reference's tags when that package is
+installed, else to <working_dir>/scalars.jsonl with the same tags.
 """
 import json
 import os
@@ -29,7 +32,7 @@ from kd6d.kd_losses import PackedTargets  # noqa: E402
 from kd6d.libs.distributed import get_rank, init_exchange, shard_batch, synchronize  # noqa: E402
 from kd6d.libs.eval_libs import valid  # noqa: E402
 from kd6d.libs.poses import ImageList  # noqa: E402
-from kd6d.libs.train_libs import build_model, build_model_teacher  # noqa: E402
+from kd6d.libs.train_libs import build_dataset, build_model, build_model_teacher, dataset_meshes  # noqa: E402
 from kd6d.models.model_kd import PoseModuleKD as PoseModule  # noqa: E402
 from kd6d.synthetic import make_batch  # noqa: E402
 
@@ -64,6 +67,29 @@ def synthetic_valid_loader(cfg, device, n_batches=2):
     return loader, meshes
 
 
+class ScalarWriter:
+    """tensorboardX.SummaryWriter when importable (train_kd.py:81 of the reference), else one JSON line per scalar."""
+
+    def __init__(self, log_dir):
+        self.tb = self.fh = None
+        try:
+            from tensorboardX import SummaryWriter
+            self.tb = SummaryWriter(log_dir)
+        except ImportError:
+            self.fh = open(os.path.join(log_dir, "scalars.jsonl"), "a")
+
+    def add_scalar(self, tag, value, step):
+        if self.tb is not None:
+            self.tb.add_scalar(tag, value, step)
+        else:
+            self.fh.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+            self.fh.flush()
+
+    def add_scalars(self, main_tag, values, step):
+        for k, v in values.items():
+            self.add_scalar("%s/%s" % (main_tag, k), v, step)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
@@ -85,11 +111,18 @@ if __name__ == "__main__":
         synchronize()
         print("gradient exchange: " + init_exchange())      # kd6d_comm_* over librccl (include/kd6d.h)
 
-    if not cfg["RUNTIME"]["SYNTHETIC"]:
-        raise SystemExit("the BOP/LINEMOD reader is outside the KD-step hot path (SURVEY.md 8(f)-4); "
-                         "run with --synthetic")
-    train_loader = synthetic_loader(cfg, device)
-    valid_loader, valid_meshes = synthetic_valid_loader(cfg, device)
+    if cfg["RUNTIME"]["SYNTHETIC"]:
+        train_loader = synthetic_loader(cfg, device)
+        valid_loader, valid_meshes = synthetic_valid_loader(cfg, device)
+    else:
+        train_loader, valid_loader = build_dataset(cfg, device)               # train_kd.py:57 of the reference
+        valid_meshes = dataset_meshes(valid_loader)
+
+        def epochs(loader):                                                    # the reference loops `while True` over epochs
+            while True:
+                for item in loader:
+                    yield item
+        train_loader = epochs(train_loader)
     cfg["KD"]["vis_dir"] = cfg["RUNTIME"]["WORKING_DIR"]
 
     print("Building teacher ......")
@@ -105,9 +138,16 @@ if __name__ == "__main__":
                                                            sum(p.numel() for p in model_t.parameters())))
         with open(os.path.join(wd, "cfg.json"), "w") as f:
             json.dump(cfg, f, indent=4, sort_keys=True, default=str)
+    logger = ScalarWriter(wd) if get_rank() == 0 else None
 
-    model.train()
     model_t.eval()
+    if get_rank() == 0 and not cfg["RUNTIME"]["SKIP_TEACHER_EVAL"]:
+        # train_kd.py:85-86 of the reference: the teacher's own accuracy before distilling from it
+        acc_t = valid(cfg_t, 0, valid_loader, model_t, device, valid_meshes)
+        seen = [a for a in acc_t[0] if a]
+        print("teacher valid: %s" % ({k: round(float(sum(a[k] for a in seen)) / len(seen), 2) for k in seen[0]}
+                                      if seen else "no objects"))
+    model.train()
     cfg_kd = cfg["KD"]
     w_cls, w_reg, w_kd = cfg["SOLVER"]["LOSS_WEIGHT_CLS"], cfg["SOLVER"]["LOSS_WEIGHT_REG"], cfg["KD"]["LOSS_WEIGHT_KD"]
     t0 = time.time()
@@ -117,17 +157,23 @@ if __name__ == "__main__":
         from kd6d.graph import GraphedKDStep
         gstep = GraphedKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd,
                               pipeline=(launch == "pipeline"))
+    MAX_ITER = cfg["SOLVER"]["MAX_ITER"]
+    pipelined = gstep is not None and gstep.pipeline
     for idx, (images, targets, _) in enumerate(train_loader):
-        if total_steps >= cfg["SOLVER"]["MAX_ITER"]:
-            if gstep is not None:
-                gstep.flush()      # pipeline mode: the last batch still waits for its student step
+        if total_steps >= MAX_ITER:
             if get_rank() == 0:
+                valid(cfg, total_steps, valid_loader, model, device, valid_meshes, logger=logger)      # train_kd.py:95-99
                 torch.save(model.state_dict(), os.path.join(wd, "final.pth"))
             print("Training finished")
             break
         if gstep is not None:
-            # the same iteration body (train_kd.py:104-140 of the reference), captured once and replayed
-            loss_dict = gstep(images, targets)
+            # the same iteration body (train_kd.py:104-140 of the reference), captured once and replayed.  Pipelined:
+            # call k runs the teacher on batch k beside the student step on batch k-1, so the LAST step is the
+            # flush of the pending batch (no new batch is consumed for it): exactly MAX_ITER optimiser steps
+            if pipelined and total_steps == MAX_ITER - 1 and gstep.pending:
+                loss_dict = gstep.flush()
+            else:
+                loss_dict = gstep(images, targets)
             if loss_dict is None:          # priming call of the pipeline: teacher only
                 continue
             total_steps += 1
@@ -148,6 +194,12 @@ if __name__ == "__main__":
             loss.backward()
             optimizer.step()          # clip_grad_norm_(GRAD_CLIP) is fused into the optimiser kernel
         scheduler.step()
+        if logger is not None and total_steps % 10 == 0:                    # train_kd.py:113-122: unweighted values
+            logger.add_scalar("training/learning_rate", optimizer.param_groups[0]["lr"], total_steps)
+            logger.add_scalar("training/loss_cls", float(loss_dict["loss_cls"]), total_steps)
+            logger.add_scalar("training/loss_reg", float(loss_dict["loss_reg"]), total_steps)
+            logger.add_scalar("training/loss_cls_reg", float(loss_dict["loss_cls"]) + float(loss_dict["loss_reg"]), total_steps)
+            logger.add_scalar("training/loss_kd", float(loss_dict["loss_kd"]), total_steps)
         if get_rank() == 0 and (total_steps % 50 == 0 or total_steps == 1):
             dt = time.time() - t0
             print("steps: %d/%d, lr:%.6f, cls:%.4f, reg:%.4f, kd:%.4f  (%.1f img/s)" % (
@@ -161,7 +213,7 @@ if __name__ == "__main__":
                 raise SystemExit("kd6d: %d in-kernel barrier waits timed out (gradients of a step are wrong); "
                                  "re-run with KD6D_BN_ONEPASS=0 KD6D_GN_ONEPASS=0" % n_to)
         if get_rank() == 0 and total_steps % VAL_FREQ == 0:
-            acc = valid(cfg, total_steps, valid_loader, model, device, valid_meshes)     # train_kd.py:148-150
+            acc = valid(cfg, total_steps, valid_loader, model, device, valid_meshes, logger=logger)     # train_kd.py:148-150
             model.train()
             seen = [a for a in acc[0] if a]
             print("valid @ %d: %s" % (total_steps, {k: round(float(sum(a[k] for a in seen)) / len(seen), 2) for k in seen[0]}
