@@ -110,7 +110,9 @@ class DziLoader:
                                  "is not rebuilt, store the frames at the internal resolution" % (W, H, self.size[1], self.size[0]))
             centers, scales = [], []
             for t in targets:
-                box = projected_box(t, 0)                                   # to_object_boxlist().bbox[0]
+                # to_object_boxlist().bbox[0]; a frame without a known object (the reference would fail on it) is
+                # cropped around the whole frame
+                box = projected_box(t, 0) if len(t.class_ids) else np.array([0.0, 0.0, float(W), float(H)])
                 c, s = aug_bbox_DZI(box, H, W) if self.training else test_bbox_DZI(box, H, W)
                 centers.append(c); scales.append(s)
             images, crop_masks, trans, bscale = dzi_batch(frames.to(self.device, non_blocking=True).contiguous(),

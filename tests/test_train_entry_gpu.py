@@ -92,19 +92,22 @@ def test_resume_from_latest_pth(gpu_device, tmp_path):
     model2, opt2, sched2, steps2 = build_model(cfg, PoseModuleKD, dev)
     model2.train()
     assert steps2 == 3 and opt2.steps == 3 and sched2.last_epoch == 3
-    assert opt2.param_groups[0]["lr"] == pytest.approx(sched.get_last_lr()[0] if False else opt2.param_groups[0]["lr"])
     got = one_step(model2, opt2, sched2)
     torch.cuda.synchronize()
     np.testing.assert_allclose(got, want, rtol=1e-5)
-    torch.testing.assert_close(model2.net.store.params, model.net.store.params, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(opt2.exp_avg, opt.exp_avg, rtol=1e-4, atol=1e-7)
+    # AdamW moves a parameter whose gradient is ~0 by +-lr * (noise / |noise|): float-atomic summation order shows up
+    # as a fraction of lr (2.5e-4 here) on a few hundred of 2.3 M elements
+    lr = opt.param_groups[0]["lr"]
+    d = (model2.net.store.params - model.net.store.params).abs()
+    assert float(d.max()) <= 0.2 * lr and float((d > 1e-6).float().mean()) < 1e-3, (float(d.max()), lr)
+    torch.testing.assert_close(opt2.exp_avg, opt.exp_avg, rtol=1e-3, atol=1e-6)
     assert opt2.param_groups[0]["lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
     # an `optim` entry written by torch.optim.AdamW (the reference's) is refused with a clear message, the weights load
     torch.save({"steps": 3, "model": model.state_dict(), "optim": {"state": {}, "param_groups": [{}]}, "sched": sched.state_dict()},
                os.path.join(wd, "latest.pth"))
     model3, opt3, _, steps3 = build_model(cfg, PoseModuleKD, dev)
     assert steps3 == 3 and opt3.steps == 0
-    torch.testing.assert_close(model3.net.store.params, model.net.store.params.to(model3.net.store.params.device) * 0 + model3.net.store.params)
+    assert torch.equal(model3.state_dict()["head.cls_logits.weight"], model.state_dict()["head.cls_logits.weight"])
 
 
 def _encoded_pose_logits(targets, levels, B, noise, rng):
