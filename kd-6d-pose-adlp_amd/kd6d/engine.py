@@ -353,7 +353,8 @@ class PoseNet:
         self.wgrad_cu_budget = 0       # CUs each forked weight gradient aims to fill (0 = the device)
         # the weight gradients of the head and FPN output convolutions as ONE grouped launch per step
         # (csrc/conv_wgrad_group.hip); created on first use, bf16 only.  wgrad_group_wgs: workgroups of that launch
-        # (0 = one per CU)
+        # (0 = one per two CUs).  Measured on the step (images/s, 64 / 128 / 256 workgroups): pipelined 4831 / 4828 /
+        # 4788, strictly sequential 4050 / 4164 / 4241 -- GraphedKDStep asks for one per CU in sequential mode
         self.wgrad_group = None
         self.grouping = False          # True while the reverse sweep is inside the section whose dW are collected
         self.use_wgrad_group = True
@@ -700,7 +701,7 @@ class PoseNet:
         assert self.training and self.arch != "darknet53"
         B, lv_all, r, oc = self.batch, self.levels, self.rows, self.out_channel
         if self.use_wgrad_group and self.dtype == torch.bfloat16 and self.wgrad_group is None:
-            self.wgrad_group = ops.WgradGroup(self.wgrad_group_wgs or ops.device_cu_count())
+            self.wgrad_group = ops.WgradGroup(self.wgrad_group_wgs or max(ops.device_cu_count() // 2, 1))
         self.grouping = self.wgrad_group is not None
         d_head_in = self.buf("d_head_in", (r, oc))
         first = True
@@ -762,6 +763,8 @@ class PoseNet:
                     self.wgrad_group.add(g, inner, dslot(pos), self.store.storage(conv.w, "grads"),
                                          self.store.storage(conv.b, "grads"), flops=conv.flops(g))
                     grouped_out.add(i)
+            # launched here, beside the FPN / backbone sweep: at the very end of the sweep the same launch cost 2-7 %
+            # of the step (it then runs with nothing beside it)
             self.flush_wgrad_group()
         self.grouping = False
         # P7 = conv(relu(P6)); P6 = conv(top feature)

@@ -55,6 +55,7 @@ class GraphedKDStep:
         snet.side_streams = ([snet.side_stream] + [torch.cuda.Stream() for _ in range(nside - 1)]
                              if concurrent and nside > 1 else None)
         snet.wgrad_cu_budget = int(ops.device_cu_count() / budget_div) if concurrent and nside > 1 else 0
+        snet.wgrad_group_wgs = ops.device_cu_count() // (2 if pipeline else 1)    # grouped head weight gradients
         self.w_cls, self.w_reg, self.w_kd = (float(w) for w in loss_weights)
         self._w = None                                     # the same weights as a device tensor
         self.cfg_kd = cfg_kd
