@@ -53,6 +53,9 @@ def parse():
     p.add_argument("--student", type=str, default="")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--frame", type=str, default="crop256", choices=["crop256", "full640"])
+    p.add_argument("--rccl-single-rank", action="store_true",
+                   help="under `torch.distributed.run --nproc-per-node 1`: run the N > 1 code path (RCCL communicator, "
+                        "the all-reduce between the two graphs, barriers) on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--no-pipeline", action="store_true",
@@ -120,9 +123,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    # KD6D_EXCHANGE_SINGLE_RANK=1 under `torch.distributed.run --nproc-per-node 1`: rehearse the N > 1 code path
-    # (RCCL communicator, the all-reduce between the two graphs, barriers) on one GPU
-    use_pg = world > 1 or (os.environ.get("KD6D_EXCHANGE_SINGLE_RANK") == "1" and "MASTER_ADDR" in os.environ)
+    use_pg = world > 1 or (args.rccl_single_rank and "MASTER_ADDR" in os.environ)
     if use_pg:
         dist.init_process_group(backend="nccl", init_method="env://")
 
@@ -144,6 +145,7 @@ def main():
     student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
     student.net.reset_parameters(seed=1)
     student = student.to(dev).train()
+    D.SINGLE_RANK_EXCHANGE = bool(args.rccl_single_rank)
     route = D.init_exchange() if use_pg else "none"      # kd6d_comm_* over librccl (include/kd6d.h)
     if use_pg:
         D.broadcast_(student.net.store.params, 0)

@@ -152,6 +152,21 @@ typedef struct kd6d_levels {
 
 int kd6d_device_cu_count(void);
 
+/* Kernel-selection options.  The dispatch rules inside the library are measured defaults; the parity tests and the
+ * per-layer benches pin one kernel family for a call through this table (process-wide, set between launches by the
+ * launching thread).  The product path sets none of them.  Names and values:
+ *   conv.halo      -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64
+ *   conv.smallc    -1 auto | 0 off | 1 the resident-patch kernel also below 2^17 pixels
+ *   conv.splitk    -1 auto | 0 off | tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
+ *   conv.tile      -1 auto | 0 register-staged kernel | 1 128x128, 2 128x64, 3 64x64 (LDS-DMA kernel)
+ *   wgrad.small    -1 auto | 0 off | 1 the narrow-layer weight-gradient kernel at any size
+ *   bn.onepass      1 | 0 two-launch BatchNorm backward     bn.onepass_max  largest x in 16-B granules (65536)
+ *   gn.onepass      1 | 0 two-launch GroupNorm backward     sinkhorn.lanes  1 | 0 general path for every point set
+ * Unknown names return KD6D_ERR_ARG. */
+int kd6d_set_option(const char* name, long long value);
+int kd6d_get_option(const char* name, long long* value);
+int kd6d_reset_options(void);
+
 /* Timing aid: stores the device's 100-MHz wall clock into *slot when the launch executes on `stream`
  * (phase boundaries inside a replayed hipGraph; tools/step_timeline.py). */
 int kd6d_mark(unsigned long long* slot, void* stream);

@@ -457,10 +457,6 @@ static inline int check_geom(const kd6d_conv_geom* g, int dtype, const char* who
 // pixels.  Pick the order with the smaller per-XCD footprint (small-M / wide-N layers: weights).
 static inline void set_tile_order(ConvParams& q, int ptiles, int BP, int BC) {
   q.n_ptiles = ptiles;
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_ORDER");
-    return e ? atoi(e) : -1;
-  }();
   const double tiles = (double)ptiles * q.n_ctiles;
   const double per_xcd = tiles / 8.0;
   const double w_tile = (double)BC * q.K * 2.0, x_tile = (double)BP * q.C * 2.0 * (q.ks > 1 ? 1.5 : 1.0);
@@ -473,7 +469,6 @@ static inline void set_tile_order(ConvParams& q, int ptiles, int BP, int BC) {
   const double c_fast = foot(q.n_ctiles, w_tile, x_tile);
   const double p_fast = foot(ptiles, x_tile, w_tile);
   q.p_fastest = p_fast < c_fast ? 1 : 0;
-  if (force >= 0) q.p_fastest = force;
 }
 
 static inline int cached_cu_count() {       // one device per process

@@ -300,15 +300,10 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
 // 3x3/s1/p1 layers with C % 64 == 0 on maps at most 64 wide, both sides packed identically.
 template <int MODE>
 bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_HALO");   // tuning aid: 0 = off, 1 = 256x128, 2 = 128x128 (4 waves), 3 = 128x128, 4 = 128x64,
-                                                // 5 = 128x32, 6 = 192x128, 9 = 64x64
-    return e ? atoi(e) : -1;
-  }();
+  const int force = (int)kd6d_opt(KD6D_OPT_CONV_HALO);
   if (force == 0) return false;
-  static const int narrow = []() { const char* e = getenv("KD6D_CONV_HALO_NARROW"); return e ? atoi(e) : 1; }();
   if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C & 63) || (p.N & 3)) return false;
-  if (p.N < 64 && (!narrow || p.N > 32)) return false;
+  if (p.N < 64 && p.N > 32) return false;
   int wmax = 0, rows = 0;
   for (int s = 0; s < g->nseg; ++s) {
     const kd6d_seg& q = g->seg[s];

@@ -1223,9 +1223,7 @@ void launch_smallc(const ConvParams& p, int halo, int total_rows, hipStream_t st
 // 3x3/s1/p1 layers with 8, 16 or 32 gather-source channels on maps up to 256 wide, both sides packed identically.
 template <int MODE>
 bool dispatch_smallc(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
-  // tuning / test aid, read per call (the parity tests flip it inside one process): 0 = off, 1 = also below 2^17 pixels
-  const char* env = getenv("KD6D_CONV_SMALLC");
-  const int force = env ? atoi(env) : -1;
+  const int force = (int)kd6d_opt(KD6D_OPT_CONV_SMALLC);
   if (force == 0) return false;
   if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C != 8 && p.C != 16 && p.C != 32) || (p.N & 3)) return false;
   if (p.stats && p.stats_groups > 0) return false;      // the group-statistics table wants the big staging buffers
@@ -1280,10 +1278,7 @@ void launch_splitk(const ConvParams& p, int nsplit, hipStream_t st) {
 // workspace (plain 16-B stores, no atomics), a small second launch sums them and applies the epilogue.
 template <int MODE>
 bool dispatch_splitk(const ConvParams& p, float* ws, size_t ws_bytes, hipStream_t st) {
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_SPLITK");   // tuning aid: 0 = off, else tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
-    return e ? atoi(e) : -1;
-  }();
+  const int force = (int)kd6d_opt(KD6D_OPT_CONV_SPLITK);
   if (force == 0 || !ws || p.stats || (p.N & 3) || p.N <= 32) return false;
   const int nk = (p.K + 63) / 64;
   auto nblocks = [&](int bp, int bc) { return ((p.M + bp - 1) / bp) * ((p.N + bc - 1) / bc); };
@@ -1307,10 +1302,7 @@ bool dispatch_splitk(const ConvParams& p, float* ws, size_t ws_bytes, hipStream_
 // bf16, N > 32: LDS-DMA kernel.  Tile by how many workgroups the layer yields (256 CUs).
 template <int MODE>
 bool dispatch_glds(const ConvParams& p, hipStream_t st) {
-  static const int force = []() {
-    const char* e = getenv("KD6D_CONV_TILE");   // tuning aid: 0 = old kernel, 1 = 128x128, 2 = 128x64, 3 = 64x64
-    return e ? atoi(e) : -1;
-  }();
+  const int force = (int)kd6d_opt(KD6D_OPT_CONV_TILE);
   if (force == 0 || p.N <= 32) return false;
   const int N = p.N, M = p.M;
   auto nblocks = [&](int bp, int bc) { return ((M + bp - 1) / bp) * ((N + bc - 1) / bc); };
@@ -1390,15 +1382,11 @@ void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
   // time ~ (steps/S) * t_step + S * |dW| / (fp32 atomic rate 1.3 TB/s), t_step ~ 1.6 us measured
   //   => S* = sqrt(steps * t_step * rate / |dW|); at most 2 workgroups per CU, because many
   //   workgroups adding into one small dW are contention-bound (measured: 2048 -> 512 = -25 %)
-  static const double scale = []() {
-    const char* e = getenv("KD6D_WGRAD_SPLIT_SCALE");
-    return e ? atof(e) : 1.0;
-  }();
   // a caller that keeps several weight gradients in flight asks each for a fraction of the device: fewer,
   // longer splits -> proportionally fewer atomic tile flushes for the same k-loop work
   const double frac = (double)p.cu_budget / (double)cached_cu_count();
   const double dw_bytes = (double)p.Cout * (double)p.J * 4.0;
-  int splits = (int)(scale * frac * sqrt((double)steps_total * 2.08e6 / dw_bytes) + 0.5);
+  int splits = (int)(frac * sqrt((double)steps_total * 2.08e6 / dw_bytes) + 0.5);
   if (splits > 512 / tiles) splits = 512 / tiles;
   if (splits > steps_total / 2) splits = steps_total / 2;
   if (splits < 1) splits = 1;
@@ -1443,8 +1431,7 @@ void launch_wgrad_small(const WgradParams& p, int R, hipStream_t st) {
 
 // wide, shallow layers: Cin in {8,16,32}, Cout <= 64, 3x3/s1/p1 or 1x1/s1, one level, >= 2^15 pixels, no bias gradient
 bool dispatch_wgrad_small(const WgradParams& p, const kd6d_conv_geom* g, hipStream_t st) {
-  const char* env = getenv("KD6D_WGRAD_SMALL");                // tuning / test aid, read per call: 0 = off, 1 = any size
-  const int force = env ? atoi(env) : -1;
+  const int force = (int)kd6d_opt(KD6D_OPT_WGRAD_SMALL);
   if (force == 0 || p.dbias != nullptr || g->nseg != 1 || p.stride != 1) return false;
   if (!((p.ks == 3 && p.pad == 1) || (p.ks == 1 && p.pad == 0))) return false;
   if ((p.Cin != 8 && p.Cin != 16 && p.Cin != 32) || p.Cout > 64 || (p.Cout & 7)) return false;

@@ -78,7 +78,7 @@ struct GRBlock {
 struct GHeader {
   int n_problems, n_tiles, n_work, n_rblocks;
   int off_problems, off_tiles, off_work, off_rblocks;
-  int debug, pad0, pad1, pad2;
+  int pad0, pad1, pad2, pad3;
 };
 
 __device__ const uint4 kd6d_wg_zero_page[16] = {};
@@ -113,7 +113,7 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 // BN result channels x [NT taps x CJ input channels], 8 waves as WN (n) x WJ (j), NS-stage LDS ring
 template <int BN, int WN, int WJ, int CJ, int NT, int NS>
 __device__ __forceinline__ void wgrad_body(const GProblem& p, const GTile& t, const GWork& w, float* __restrict__ slab,
-                                           char* smem, int debug) {
+                                           char* smem) {
   constexpr int NI = BN / WN / 16;                 // dY fragments per wave
   constexpr int CW = CJ / WJ;                      // input channels per wave and tap
   constexpr int JI = CW / 16;
@@ -228,7 +228,6 @@ __device__ __forceinline__ void wgrad_body(const GProblem& p, const GTile& t, co
   };
   const bool need_y = kyo != 0;
   auto issue = [&](int stage, int step) {
-    if (debug & 1) return;
     if (cur_level < 0 || step >= lv_next) enter_level(step);
     char* tbase = smem + stage * STAGE + (is_x ? DBYTES : 0);
     const bool edge = (lv_q0 < PADX) | (lv_q0 + KSTEP + PADX > lv_P);
@@ -309,7 +308,7 @@ __device__ __forceinline__ void wgrad_body(const GProblem& p, const GTile& t, co
       if (s2 >= NS) s2 -= NS;
       issue(s2, w.step_lo + i + NS - 1);
     }
-    if (!(debug & 2)) {
+    {
       const int sb = stage * STAGE;
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
@@ -364,10 +363,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_group_kernel(const char* __res
   const GProblem& p = reinterpret_cast<const GProblem*>(plan + h->off_problems)[t.problem];
   float* my = slab + (size_t)blockIdx.x * kSlabStride;
   switch (t.variant) {
-    case V_128x3: wgrad_body<128, 2, 4, 128, 3, 4>(p, t, w, my, smem, h->debug); break;
-    case V_16x3: wgrad_body<16, 1, 8, 128, 3, 4>(p, t, w, my, smem, h->debug); break;
-    case V_128x1: wgrad_body<128, 2, 4, 128, 1, 4>(p, t, w, my, smem, h->debug); break;
-    default: wgrad_body<16, 1, 8, 128, 1, 4>(p, t, w, my, smem, h->debug); break;
+    case V_128x3: wgrad_body<128, 2, 4, 128, 3, 4>(p, t, w, my, smem); break;
+    case V_16x3: wgrad_body<16, 1, 8, 128, 3, 4>(p, t, w, my, smem); break;
+    case V_128x1: wgrad_body<128, 2, 4, 128, 1, 4>(p, t, w, my, smem); break;
+    default: wgrad_body<16, 1, 8, 128, 1, 4>(p, t, w, my, smem); break;
   }
 }
 
@@ -529,7 +528,6 @@ extern "C" int64_t kd6d_wgrad_group_plan(const kd6d_wgrad_item* items, int n_ite
   }
   GHeader h;
   memset(&h, 0, sizeof(h));
-  { const char* e = getenv("KD6D_WG_DEBUG"); h.debug = e ? atoi(e) : 0; }
   h.n_problems = n_items; h.n_tiles = (int)tiles.size(); h.n_work = (int)work.size(); h.n_rblocks = (int)rblocks.size();
   auto align = [](size_t v) { return (v + 63) / 64 * 64; };
   size_t off = align(sizeof(GHeader));

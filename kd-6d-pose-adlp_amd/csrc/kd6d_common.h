@@ -35,6 +35,23 @@ void kd6d_set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
+// ---- kernel-selection options (kd6d_set_option, include/kd6d.h) -------------------------------------------------
+// One table instead of environment variables: the parity tests and the per-layer benches select a kernel family
+// through the C ABI, inside one process; the product path never sets any of them.
+enum Kd6dOption {
+  KD6D_OPT_CONV_HALO = 0,      // -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64
+  KD6D_OPT_CONV_SMALLC,        // -1 auto | 0 off | 1 also below 2^17 pixels
+  KD6D_OPT_CONV_SPLITK,        // -1 auto | 0 off | tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
+  KD6D_OPT_CONV_TILE,          // -1 auto | 0 register-staged kernel | 1 128x128, 2 128x64, 3 64x64 (LDS-DMA kernel)
+  KD6D_OPT_WGRAD_SMALL,        // -1 auto | 0 off | 1 any size
+  KD6D_OPT_BN_ONEPASS,         // 1 | 0: the two-launch BN backward even when the caller passes a barrier counter
+  KD6D_OPT_BN_ONEPASS_MAX,     // largest x (16-B granules) on the one-launch BN backward
+  KD6D_OPT_GN_ONEPASS,         // 1 | 0: the two-launch GN backward
+  KD6D_OPT_SINKHORN_LANES,     // 1 | 0: every set on the general (one softmin after the other) path
+  KD6D_OPT_COUNT
+};
+long long kd6d_opt(int id);
+
 // ---- scalar conversions ---------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -17,6 +17,44 @@ void kd6d_set_error(const char* fmt, ...) {
 extern "C" const char* kd6d_last_error(void) { return g_err; }
 extern "C" int kd6d_abi_version(void) { return KD6D_ABI_VERSION; }
 
+// Kernel-selection options: see Kd6dOption in kd6d_common.h.  Plain loads / stores of aligned 64-bit words; the
+// caller sets them between launches from the thread that launches.
+namespace {
+struct OptRow { const char* name; long long def; };
+const OptRow kOptRows[KD6D_OPT_COUNT] = {
+    {"conv.halo", -1},  {"conv.smallc", -1},       {"conv.splitk", -1}, {"conv.tile", -1},     {"wgrad.small", -1},
+    {"bn.onepass", 1},  {"bn.onepass_max", 65536}, {"gn.onepass", 1},   {"sinkhorn.lanes", 1},
+};
+long long g_opt[KD6D_OPT_COUNT] = {-1, -1, -1, -1, -1, 1, 65536, 1, 1};
+int opt_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < KD6D_OPT_COUNT; ++i)
+    if (strcmp(name, kOptRows[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+long long kd6d_opt(int id) { return g_opt[id]; }
+
+extern "C" int kd6d_set_option(const char* name, long long value) {
+  const int i = opt_index(name);
+  KD6D_CHECK_ARG(i >= 0, "kd6d_set_option: unknown option '%s'", name ? name : "(null)");
+  g_opt[i] = value;
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_get_option(const char* name, long long* value) {
+  const int i = opt_index(name);
+  KD6D_CHECK_ARG(i >= 0 && value, "kd6d_get_option: unknown option '%s'", name ? name : "(null)");
+  *value = g_opt[i];
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_reset_options(void) {
+  for (int i = 0; i < KD6D_OPT_COUNT; ++i) g_opt[i] = kOptRows[i].def;
+  return KD6D_OK;
+}
+
 // Number of compute units of the current device (host query, no sync).
 extern "C" int kd6d_device_cu_count(void) {
   int dev = 0, n = 0;

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
 // mean = s/n, rstd = rsqrt(max(q/n - mean^2, 0) + eps) with n = H*W*C/G.
 // ---------------------------------------------------------------------------
 // rows of one (level, sample) handled by a reduction workgroup (GnGeom::chunk_rows)
-int gn_chunk_rows() { static const int v = []() { const char* e = getenv("KD6D_GN_ROWS"); return e ? atoi(e) : 128; }(); return v; }
+int gn_chunk_rows() { return 128; }
 
 struct GnGeom {
   int nseg, batch, C, G;
@@ -1391,19 +1391,16 @@ int gn_onepass_capacity() {
   static const int v = resident_workgroups(gn_relu_bwd_onepass_kernel<T, TX>, 16384);
   return v;
 }
-// KD6D_BN_ONEPASS=0: the two-launch BN backward even when the caller passes a barrier counter; read per call
-bool bn_onepass() { const char* e = getenv("KD6D_BN_ONEPASS"); return !(e && e[0] == '0'); }
+// option bn.onepass = 0: the two-launch BN backward even when the caller passes a barrier counter
+bool bn_onepass() { return kd6d_opt(KD6D_OPT_BN_ONEPASS) != 0; }
 // Largest tensor (16-B granules of x) that takes the one-launch BN backward.  Measured on an MI355X
 // (tools/bench_norm.py): up to ~128 workgroups the barrier is cheaper than a second launch (11-13 us against
 // 15 us per layer); at 256-512 workgroups publishing and collecting the partial sums through device-scope
 // returning atomics costs more than re-reading x and dz (27-29 us against 20 us), so those keep the pair.
-// KD6D_BN_ONEPASS_MAX=<granules> overrides (tests drive 512-workgroup grids through it); read per call.
-long long bn_onepass_max_granules() {
-  const char* e = getenv("KD6D_BN_ONEPASS_MAX");
-  return e ? atoll(e) : 65536;
-}
-// KD6D_GN_ONEPASS=0: the two-launch GN backward (reduce, apply); read per call
-bool gn_onepass() { const char* e = getenv("KD6D_GN_ONEPASS"); return !(e && e[0] == '0'); }
+// Option bn.onepass_max = <granules> overrides the 65536 (tests drive 512-workgroup grids through it).
+long long bn_onepass_max_granules() { return kd6d_opt(KD6D_OPT_BN_ONEPASS_MAX); }
+// option gn.onepass = 0: the two-launch GN backward (reduce, apply)
+bool gn_onepass() { return kd6d_opt(KD6D_OPT_GN_ONEPASS) != 0; }
 
 long long gn_rows(const GnGeom& gm) {
   long long r = 0;

@@ -398,9 +398,8 @@ extern "C" int kd6d_sinkhorn_div_fwd_bwd(const float* xs, const float* alpha, co
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  // KD6D_SINKHORN_LANES=0: every set on the general (one softmin after the other) path; read per call (tests)
-  const char* lanes_env = getenv("KD6D_SINKHORN_LANES");
-  const int slow = lanes_env && lanes_env[0] == '0';
+  // option sinkhorn.lanes = 0: every set on the general (one softmin after the other) path (tests)
+  const int slow = kd6d_opt(KD6D_OPT_SINKHORN_LANES) == 0;
   hipLaunchKernelGGL(sinkhorn_small_kernel, dim3(n_images), dim3(64 * kWaves), lds, st, xs, alpha,
                      s_start, s_cnt, yt, beta, t_start, t_cnt, blur, scaling, reach, loss_img, valid_img, loss_kp,
                      grad_xs, grad_alpha, slow);

@@ -58,6 +58,9 @@ SIGNATURES = {
     "kd6d_abi_version": [],
     "kd6d_device_cu_count": [],
     "kd6d_mark": [_P, _P],
+    "kd6d_set_option": [ctypes.c_char_p, ctypes.c_longlong],
+    "kd6d_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)],
+    "kd6d_reset_options": [],
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],

@@ -232,8 +232,8 @@ class BatchNorm:
 
 class ConvBlock:
     """conv(no bias) + BN + LeakyReLU(0.1)  (backbone/common.py:250-324)."""
-    # up to 256 workgroups adding into one channel; beyond that a separate pass wins (KD6D_FUSE_STATS_ROWS: tuning aid)
-    FUSE_STATS_MAX_ROWS = int(os.environ.get("KD6D_FUSE_STATS_ROWS", 1 << 15))
+    # up to 256 workgroups adding into one channel; beyond that a separate pass wins
+    FUSE_STATS_MAX_ROWS = 1 << 15
 
     @staticmethod
     def bwd_replicas(rows):
@@ -359,9 +359,9 @@ class PoseNet:
         self.grouping = False          # True while the reverse sweep is inside the section whose dW are collected
         self.use_wgrad_group = True
         self.wgrad_group_wgs = 0
-        self.fuse_pool = os.environ.get("KD6D_FUSE_POOL", "1") != "0"   # BN + act + maxpool as one kernel (training)
+        self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
-        self.pair_towers = int(os.environ.get("KD6D_PAIR_TOWERS", "1"))
+        self.pair_towers = 1
         self._side_rr = 0
         feat, oc = BACKBONE_CFG[arch]
         self.out_channel = oc

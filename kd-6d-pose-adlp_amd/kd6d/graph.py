@@ -45,11 +45,11 @@ class GraphedKDStep:
         self.teacher_stream = torch.cuda.Stream() if (concurrent or pipeline) else None
         # ... with several weight gradients in flight, each sized for a share of the CUs: the same k-loop work
         # with proportionally fewer atomic dW-tile flushes (measured: 1 -> 4 streams = +8 % on the step)
-        # (KD6D_WGRAD_STREAMS / KD6D_WGRAD_BUDGET_DIV: tuning aids.  Swept on the closing state of round 1, medians of
+        # (WGRAD_STREAMS / WGRAD_BUDGET_DIV.  Swept on the closing state of round 1, medians of
         #  3 runs: 4 streams at CUs/4 4539 images/s, CUs/3 4566, CUs/2 4595-4640, CUs/1.5 4597, whole device 4529;
         #  3 streams 4330-4430, 5 streams 4140-4200, 6-8 streams 4340)
-        nside = int(os.environ.get("KD6D_WGRAD_STREAMS", self.WGRAD_STREAMS))
-        budget_div = float(os.environ.get("KD6D_WGRAD_BUDGET_DIV", self.WGRAD_BUDGET_DIV[bool(pipeline)]))
+        nside = self.WGRAD_STREAMS
+        budget_div = self.WGRAD_BUDGET_DIV[bool(pipeline)]
         snet = student.net
         snet.side_stream = torch.cuda.Stream() if concurrent else None
         snet.side_streams = ([snet.side_stream] + [torch.cuda.Stream() for _ in range(nside - 1)]

@@ -34,13 +34,16 @@ def synchronize():
         dist.barrier()
 
 
+# bench.py --rccl-single-rank sets this: a one-rank process group still runs the exchange (a rehearsal of the RCCL
+# path -- communicator set-up, the collective between the two replayed graphs, the barriers -- on a box with one GPU)
+SINGLE_RANK_EXCHANGE = False
+
+
 def exchange_active():
-    """True when the per-step gradient exchange has to run: more than one rank, or a one-rank process group with
-    KD6D_EXCHANGE_SINGLE_RANK=1 (a rehearsal of the RCCL path -- communicator set-up, the collective between the
-    two replayed graphs, the barriers -- on a box with one GPU)."""
+    """True when the per-step gradient exchange has to run: more than one rank, or SINGLE_RANK_EXCHANGE."""
     if not dist.is_available() or not dist.is_initialized():
         return False
-    return dist.get_world_size() > 1 or os.environ.get("KD6D_EXCHANGE_SINGLE_RANK") == "1"
+    return dist.get_world_size() > 1 or SINGLE_RANK_EXCHANGE
 
 
 _comm = None            # kd6d_comm* of this process (ctypes.c_void_p) once init_exchange() succeeded

@@ -150,6 +150,33 @@ def conv2d_wgrad(geom, x, dy, dw, flops=0, dbias=None, cu_budget=0):
     return dw
 
 
+def set_option(name, value):
+    """kd6d_set_option (include/kd6d.h): pin a kernel family for the calls that follow; tests and benches only."""
+    check(lib.kd6d_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = ctypes.c_longlong(0)
+    check(lib.kd6d_get_option(name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
+class option:
+    """`with ops.option("conv.smallc", 1): ...` -- the option is put back on exit."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
 def device_cu_count():
     n = lib.kd6d_device_cu_count()
     if n <= 0:

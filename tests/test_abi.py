@@ -47,3 +47,32 @@ def test_argument_checks_fail_loudly_without_gpu():
     except _lib.Kd6dError as e:
         assert "null pointer" in str(e)
     assert lib.kd6d_sinkhorn_max_points() >= 64
+
+
+def test_kernel_selection_options_table():
+    """kd6d_set_option / kd6d_get_option / kd6d_reset_options (host-only state): the documented names exist with the
+    documented defaults, unknown names are refused, and no KD6D_* environment variable is read by the library or the
+    host package any more."""
+    import pytest
+    from kd6d import ops
+    defaults = {"conv.halo": -1, "conv.smallc": -1, "conv.splitk": -1, "conv.tile": -1, "wgrad.small": -1,
+                "bn.onepass": 1, "bn.onepass_max": 65536, "gn.onepass": 1, "sinkhorn.lanes": 1}
+    ops.lib.kd6d_reset_options()
+    for k, v in defaults.items():
+        assert ops.get_option(k) == v, k
+    with ops.option("bn.onepass_max", 1 << 40):
+        assert ops.get_option("bn.onepass_max") == 1 << 40
+    assert ops.get_option("bn.onepass_max") == 65536
+    with pytest.raises(RuntimeError, match="unknown option"):
+        ops.set_option("conv.nonsense", 1)
+    header = open(os.path.join(ROOT, "include", "kd6d.h")).read()
+    assert all(k in header for k in defaults)
+    pkg = os.path.join(ROOT, "kd-6d-pose-adlp_amd")
+    for d, _, files in os.walk(pkg):
+        if os.sep + "build" in d:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".h", ".py")):
+                src = open(os.path.join(d, f)).read()
+                assert "getenv(" not in src, f
+                assert not re.search(r"environ[^\n]*KD6D_", src), f

@@ -25,6 +25,26 @@ def _ops():
     return ops
 
 
+def _option(name, value):
+    """Pin a kernel family through kd6d_set_option for the rest of this test (put back by the fixture below)."""
+    ops = _ops()
+    _RESTORE.append((name, ops.get_option(name)))
+    ops.set_option(name, value)
+
+
+_RESTORE = []
+
+
+@pytest.fixture(autouse=True)
+def _restore_options():
+    yield
+    if _RESTORE:
+        ops = _ops()
+        while _RESTORE:
+            name, old = _RESTORE.pop()
+            ops.set_option(name, old)
+
+
 def _tol(dtype, stored):
     # stored=True: result was rounded to `dtype` on the way out
     if dtype == torch.float32:
@@ -270,9 +290,9 @@ def test_conv_wgrad(gpu_device, dtype, case):
     (3, 16, 24, 3, [(9, 7)]),          # ragged: tiles shorter than the image, odd width
     (2, 8, 8, 3, [(3, 300)]),          # wider than 256: stays on the general kernel
 ])
-def test_conv_wgrad_small_layers(gpu_device, case, monkeypatch):
+def test_conv_wgrad_small_layers(gpu_device, case):
     ops = _ops()
-    monkeypatch.setenv("KD6D_WGRAD_SMALL", "1")
+    _option("wgrad.small", 1)
     dtype = torch.bfloat16
     B, Cin, Cout, k, levels = case
     g = torch.Generator().manual_seed(3 + Cout)
@@ -338,11 +358,10 @@ def test_conv_fwd_fused_statistics(gpu_device, dtype, case):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] == 3 and c[4] == 1])
-def test_conv_resident_patch_kernel_on_every_small_c_case(gpu_device, dtype, case, monkeypatch):
-    """The resident-patch kernel (C in {8,16,32}) is dispatched from 2^17 pixels up; KD6D_CONV_SMALLC=1 (read per
-    call) lifts the size rule so the small / ragged 3x3 CONV_CASES (multi-level, N tails, two channel tiles) run
+def test_conv_resident_patch_kernel_on_every_small_c_case(gpu_device, dtype, case):
+    """The resident-patch kernel (C in {8,16,32}) is dispatched from 2^17 pixels up; option conv.smallc = 1 lifts the size rule so the small / ragged 3x3 CONV_CASES (multi-level, N tails, two channel tiles) run
     through it as well -- forward, dgrad (where its gather source is narrow) and the fused BatchNorm statistics."""
-    monkeypatch.setenv("KD6D_CONV_SMALLC", "1")
+    _option("conv.smallc", 1)
     test_conv_fwd_plain(gpu_device, dtype, case)
     test_conv_dgrad(gpu_device, dtype, case)
     B, Cin, Cout, k, stride, levels = case
@@ -381,12 +400,12 @@ MIXED = [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, False)
 @pytest.mark.parametrize("dtype,xf32", MIXED)
 @pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64), (8, 300000), (16, 70001)])
 @pytest.mark.parametrize("onepass", [False, True])
-def test_batchnorm_train_fwd_bwd(gpu_device, monkeypatch, dtype, xf32, C, rows, onepass):
+def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows, onepass):
     """onepass: the backward as one launch whose workgroups meet at an in-kernel barrier (kd6d_bn_train_bwd with a
     counter; the size limit is lifted so that the long tensors run 512-workgroup grids) against the reduce + apply
     pair."""
     ops = _ops()
-    monkeypatch.setenv("KD6D_BN_ONEPASS_MAX", str(1 << 40))
+    _option("bn.onepass_max", 1 << 40)
     dev = gpu_device
     g = torch.Generator().manual_seed(C + rows)
     x = round_to(torch.randn(rows, C, generator=g) * 2 + 0.5, torch.float32 if xf32 else dtype)
@@ -434,14 +453,14 @@ def test_batchnorm_train_fwd_bwd(gpu_device, monkeypatch, dtype, xf32, C, rows, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,xf32", [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 16, 16, 64), (2, 64, 64, 16), (16, 64, 64, 8), (1, 2, 2, 256)])
-def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, monkeypatch, dtype, xf32, B, H, W, C):
+def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, dtype, xf32, B, H, W, C):
     """BN(train)+LeakyReLU+MaxPool2d(2,2) as one kernel (darknet.py:94-97 behind a ConvBlock): the pooled output is
     bit-identical to bn_train_fwd -> maxpool2_fwd, the backward matches bn_train_bwd(maxpool2_bwd(.)) up to the
     order of the fp32 reductions, and both agree with torch autograd in float64.  Ties inside a window (common in
     bf16) exercise the first-maximum rule."""
     ops = _ops()
     dev = gpu_device
-    monkeypatch.setenv("KD6D_BN_ONEPASS_MAX", str(1 << 40))      # the one-launch backward at every size
+    _option("bn.onepass_max", 1 << 40)      # the one-launch backward at every size
     if dtype == torch.float32 and C % 4:
         pytest.skip("granule")
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + C)
@@ -506,14 +525,14 @@ def test_bn_pool_fused_pair_equals_bn_then_maxpool(gpu_device, monkeypatch, dtyp
         torch.testing.assert_close(fdg.double(), gr.grad, rtol=1e-3, atol=1e-3 * gs)
 
 
-def test_in_kernel_barriers_under_repetition(gpu_device, monkeypatch):
+def test_in_kernel_barriers_under_repetition(gpu_device):
     """The one-launch BN / GN backward kernels exchange partial sums across workgroups inside the launch.  300
     back-to-back launches each (512- and 274-workgroup BN grids, 8-workgroup GN sibling groups) must all reproduce
     the two-launch result: a workgroup that left the barrier before a sibling's partial sum was visible would miss
     ~1/274 of a total, far outside the tolerance.  No barrier may time out."""
     ops = _ops()
     dev = gpu_device
-    monkeypatch.setenv("KD6D_BN_ONEPASS_MAX", str(1 << 40))
+    _option("bn.onepass_max", 1 << 40)
     bf = torch.bfloat16
     g = torch.Generator().manual_seed(99)
     for C, rows in [(16, 70001), (64, 65536)]:
@@ -553,14 +572,14 @@ def test_in_kernel_barriers_under_repetition(gpu_device, monkeypatch):
     ops.gn_relu_fwd(x, y, hw, B, G, gamma, beta, 1e-5, stats)
     ref = None
     for it in range(301):
-        os.environ["KD6D_GN_ONEPASS"] = "0" if it == 0 else "1"
+        ops.set_option("gn.onepass", 0 if it == 0 else 1)
         try:
             gsum = torch.empty(ops.gn_bwd_workspace_floats(len(levels), B, G), device=dev)
             dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
             dx = torch.empty(rows, C, dtype=bf, device=dev)
             ops.gn_relu_bwd(x, dz, dx, hw, B, G, gamma, beta, stats, gsum, dg, db)
         finally:
-            os.environ.pop("KD6D_GN_ONEPASS", None)
+            ops.set_option("gn.onepass", 1)
         if it == 0:
             ref = (dx.float(), dg.clone())
         else:
@@ -587,12 +606,12 @@ def test_colstats_any_channel_count(gpu_device, dtype, C, rows):
 @pytest.mark.parametrize("C", [128, 256])
 @pytest.mark.parametrize("levels,onepass", [([(6, 6), (3, 3), (2, 2), (1, 1)], "1"), ([(6, 6), (3, 3), (2, 2), (1, 1)], "0"),
                                             ([(32, 32), (16, 12), (5, 5)], "1"), ([(32, 32), (16, 12), (5, 5)], "0")])
-def test_groupnorm_relu_fwd_bwd(gpu_device, monkeypatch, dtype, xf32, C, levels, onepass):
+def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C, levels, onepass):
     """onepass "1": the backward is one kernel whose workgroups of a (level, image) meet at an in-kernel barrier
     (32x32 levels span 8..32 workgroups); "0": the reduce + apply pair."""
     ops = _ops()
     dev = gpu_device
-    monkeypatch.setenv("KD6D_GN_ONEPASS", onepass)
+    _option("gn.onepass", int(onepass))
     B, G = 3, 32
     g = torch.Generator().manual_seed(C)
     xdt = torch.float32 if xf32 else dtype
@@ -678,12 +697,12 @@ def test_pool_upsample_eltwise(gpu_device, dtype):
 
 @pytest.mark.parametrize("reach", [0.5, None])
 @pytest.mark.parametrize("lanes", ["1", "0"])
-def test_sinkhorn_kernel_vs_oracle(gpu_device, monkeypatch, reach, lanes):
+def test_sinkhorn_kernel_vs_oracle(gpu_device, reach, lanes):
     """fp32 kernel vs fp64 oracle: loss rtol 1e-4, grads rtol 2e-3.  lanes "1": sets of up to 16
     points run their four softmins side by side on the wave's four 16-lane rows (the 20 / 17-point images still take
     the general path); "0": the general path for every image."""
     ops = _ops()
-    monkeypatch.setenv("KD6D_SINKHORN_LANES", lanes)
+    _option("sinkhorn.lanes", int(lanes))
     from oracle.sinkhorn_ref import kd_loss_images
     r = np.random.default_rng(0)
     counts_s = [10, 0, 9, 12, 1, 10, 20, 16, 3]

@@ -100,7 +100,11 @@ def test_resume_from_latest_pth(gpu_device, tmp_path):
     lr = opt.param_groups[0]["lr"]
     d = (model2.net.store.params - model.net.store.params).abs()
     assert float(d.max()) <= 0.2 * lr and float((d > 1e-6).float().mean()) < 1e-3, (float(d.max()), lr)
-    torch.testing.assert_close(opt2.exp_avg, opt.exp_avg, rtol=1e-3, atol=1e-6)
+    # the moments after step 4: a lost or stale state would differ by 0.9 * m3 (relative O(1)); what is left between two
+    # runs of the same step is summation-order noise (measured: 2 of 2.24 M elements off by 1.3e-6 at |m| < 3e-4)
+    for a, b in ((opt2.exp_avg, opt.exp_avg), (opt2.exp_avg_sq, opt.exp_avg_sq)):
+        assert float((a - b).norm() / b.norm()) < 1e-4
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
     assert opt2.param_groups[0]["lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
     # an `optim` entry written by torch.optim.AdamW (the reference's) is refused with a clear message, the weights load
     torch.save({"steps": 3, "model": model.state_dict(), "optim": {"state": {}, "param_groups": [{}]}, "sched": sched.state_dict()},

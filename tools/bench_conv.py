@@ -67,7 +67,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--stats", type=int, default=-1, help="fwd: fused statistics (0 = per channel, G = groups), fp32 output")
+    ap.add_argument("--opt", action="append", default=[], help="kernel-selection option name=value (kd6d_set_option)")
     a = ap.parse_args()
+    for kv in a.opt:
+        k_, v_ = kv.split("=")
+        ops.set_option(k_, int(v_))
     global EAGER
     EAGER = a.eager
     dev = torch.device("cuda:0")

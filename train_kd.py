@@ -106,6 +106,10 @@ if __name__ == "__main__":
         raise SystemExit("the kd6d step runs on MI355X only (--running_device cuda); the CPU restatement "
                          "lives in oracle/ and is test infrastructure")
     torch.cuda.set_device(local_rank)
+    if cfg["RUNTIME"].get("TWO_LAUNCH_NORM_BWD"):
+        from kd6d import ops
+        ops.set_option("bn.onepass", 0)
+        ops.set_option("gn.onepass", 0)
     if cfg["RUNTIME"]["DISTRIBUTED"]:
         torch.distributed.init_process_group(backend="nccl", init_method="env://")
         synchronize()
@@ -211,7 +215,7 @@ if __name__ == "__main__":
             n_to = lib.kd6d_barrier_timeouts()
             if n_to != 0:
                 raise SystemExit("kd6d: %d in-kernel barrier waits timed out (gradients of a step are wrong); "
-                                 "re-run with KD6D_BN_ONEPASS=0 KD6D_GN_ONEPASS=0" % n_to)
+                                 "re-run with --two_launch_norm_bwd" % n_to)
         if get_rank() == 0 and total_steps % VAL_FREQ == 0:
             acc = valid(cfg, total_steps, valid_loader, model, device, valid_meshes, logger=logger)     # train_kd.py:148-150
             model.train()
