@@ -167,6 +167,19 @@ int kd6d_set_option(const char* name, long long value);
 int kd6d_get_option(const char* name, long long* value);
 int kd6d_reset_options(void);
 
+/* Step prologue: zero up to KD6D_MAX_ZERO device regions (16-B aligned, sizes multiples of 4 bytes; a size of 0
+ * skips the entry) and add 1 to each of n_counter (<= 256) int64 counters, in ONE launch.  Stands where the
+ * reference's step has optimizer.zero_grad() (train_kd.py:104) and BatchNorm's num_batches_tracked += 1; here the
+ * same launch also clears the statistics arena, the dense head gradient and the loss-side slot arrays. */
+#define KD6D_MAX_ZERO 8
+typedef struct kd6d_zero_list {
+  int32_t n;
+  int32_t pad_;
+  void* ptr[KD6D_MAX_ZERO];
+  int64_t bytes[KD6D_MAX_ZERO];
+} kd6d_zero_list;
+int kd6d_zero_regions(const kd6d_zero_list* list, long long* counter, int n_counter, void* stream);
+
 /* Timing aid: stores the device's 100-MHz wall clock into *slot when the launch executes on `stream`
  * (phase boundaries inside a replayed hipGraph; tools/step_timeline.py). */
 int kd6d_mark(unsigned long long* slot, void* stream);

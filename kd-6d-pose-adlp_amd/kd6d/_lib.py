@@ -44,6 +44,13 @@ class WgradItem(ctypes.Structure):
 
 
 MAX_GT = 4
+MAX_ZERO = 8
+
+
+class ZeroList(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("pad_", ctypes.c_int32), ("ptr", ctypes.c_void_p * MAX_ZERO),
+                ("bytes", ctypes.c_int64 * MAX_ZERO)]
+
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -61,6 +68,7 @@ SIGNATURES = {
     "kd6d_set_option": [ctypes.c_char_p, ctypes.c_longlong],
     "kd6d_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)],
     "kd6d_reset_options": [],
+    "kd6d_zero_regions": [ctypes.POINTER(ZeroList), _P, _I, _P],
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],

@@ -598,12 +598,19 @@ class PoseNet:
         # darknet.py:125-135: out4 = stage5(stage4(out3))
         return [feats[0], feats[1], feats[2], feats[4]]
 
-    def forward(self, images):
-        """images (B,3,H,W) fp32 NCHW on device -> packed logits cls (rows,16) fp32, reg (rows,240) fp32."""
+    def scratch_region(self):
+        """The part of the statistics arena a step has to zero (None until a first forward has sized it)."""
+        if self.scratch_buf is None or self._scratch_size == 0:
+            return None
+        return self.scratch_buf[:max(self._scratch_size, 8)]
+
+    def forward(self, images, scratch_zeroed=False):
+        """images (B,3,H,W) fp32 NCHW on device -> packed logits cls (rows,16) fp32, reg (rows,240) fp32.
+        scratch_zeroed: the caller's step prologue (ops.zero_many) already cleared scratch_region()."""
         B, _, H, W = images.shape
         self.prepare_weights(need_dgrad=self.training)
         self.tape = []
-        if self.scratch_buf is not None:
+        if self.scratch_buf is not None and not scratch_zeroed:
             # one memset per step: every atomically accumulated statistic lives here (only the part in use)
             self.scratch_buf[:max(self._scratch_size, 8)].zero_()
         x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=self.buf("input", (B * H * W, 8)))

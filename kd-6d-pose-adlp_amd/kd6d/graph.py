@@ -88,8 +88,7 @@ class GraphedKDStep:
             return DeferredTeacher(pred, self.teacher_stream)
 
     def _forward_backward(self):
-        ops.mark("step.start")
-        self.student.zero_grad()
+        ops.mark("step.start")              # (step_losses opens with the step's zero_grad)
         if not self.pipeline:
             return self._student_step(self._teacher(self.images, self.tgt))
         nxt = self._teacher(self.images_nxt, self.tgt_nxt)       # batch k, beside ...
@@ -181,6 +180,9 @@ class GraphedKDStep:
         self.student._defer_allreduce = True
         if self.pipeline and self._blocks is None:
             self._make_blocks()
+        elif not self.pipeline and getattr(self.teacher, "_teacher_flats", None) is None:
+            from .kd_losses import teacher_flats     # caller-owned teacher outputs: cleared by the teacher's prologue
+            self.teacher._teacher_flats = teacher_flats(self.images.tensors.shape[0], self.images.tensors.device)
         snap = self._snapshot()                              # the warm-up steps below must not train
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

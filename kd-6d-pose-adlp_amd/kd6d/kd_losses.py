@@ -114,6 +114,26 @@ class PackedTargets:
         self._rebind()
 
 
+_SLOT_STARTS = {}
+
+
+def _slot_starts(batch, cap, device):
+    """int32 [0, cap, 2*cap, ...]: constant per (batch, cap, device), built once (it used to cost two torch launches
+    inside every replayed step)."""
+    key = (batch, cap, str(device))
+    t = _SLOT_STARTS.get(key)
+    if t is None:
+        t = _SLOT_STARTS[key] = torch.arange(batch, dtype=torch.int32, device=device) * cap
+    return t
+
+
+def teacher_flats(batch, device, cap=None):
+    """Caller-owned output buffers of teacher_select: fp32 (n*48) and int32 (n + batch rounded up to 4)."""
+    n = batch * (cap or CAP)
+    return (torch.zeros(n * 48, dtype=torch.float32, device=device),
+            torch.zeros(n + (batch + 3) // 4 * 4, dtype=torch.int32, device=device))
+
+
 class TeacherKnowledge(dict):
     """pred_t of the reference (models/model_kd.py:83-92).  The device-side slot arrays are what the
     student step consumes; the reference-named entries are materialised (with a sync) on demand."""
@@ -123,7 +143,7 @@ class TeacherKnowledge(dict):
         self.t_cnt, self.t_kp, self.t_score, self.t_row = t_cnt, t_kp, t_score, t_row
         self.t_kp_norm, self.t_beta = t_kp_norm, t_beta
         self.cap, self.batch = cap, batch
-        self.t_start = torch.arange(batch, dtype=torch.int32, device=t_cnt.device) * cap
+        self.t_start = _slot_starts(batch, cap, t_cnt.device)
         self.flats = flats            # (fp32, int32) buffers all the slot arrays are views of
 
     @staticmethod
@@ -137,68 +157,6 @@ class TeacherKnowledge(dict):
         """Persistent copy (own storage) that `copy_from` refreshes: the double buffer of the step pipeline."""
         wf, wi = (t.clone() for t in self.flats)
         return TeacherKnowledge.from_flats(wf, wi, self.batch, self.cap)
-
-    def copy_from(self, other):
-        self.mask.copy_(other.mask, non_blocking=True)
-        self.flat_f.copy_(other.flat_f, non_blocking=True)
-        self.flat_i.copy_(other.flat_i, non_blocking=True)
-
-    def rebind_storage(self, mask, flat_f, flat_i):
-        """Move the three device buffers into caller-owned storage of the same shapes (contents are copied)."""
-        for new, old in ((mask, self.mask), (flat_f, self.flat_f), (flat_i, self.flat_i)):
-            assert new.shape == old.shape and new.dtype == old.dtype
-            new.copy_(old)
-        self.mask, self.flat_f, self.flat_i = mask, flat_f, flat_i
-        self._rebind()
-
-
-class TeacherKnowledge(dict):
-    """pred_t of the reference (models/model_kd.py:83-92).  The device-side slot arrays are what the
-    student step consumes; the reference-named entries are materialised (with a sync) on demand."""
-
-    def __init__(self, t_cnt, t_kp, t_score, t_row, t_kp_norm, t_beta, cap, batch, flats=None):
-        super().__init__()
-        self.t_cnt, self.t_kp, self.t_score, self.t_row = t_cnt, t_kp, t_score, t_row
-        self.t_kp_norm, self.t_beta = t_kp_norm, t_beta
-        self.cap, self.batch = cap, batch
-        self.t_start = torch.arange(batch, dtype=torch.int32, device=t_cnt.device) * cap
-        self.flats = flats            # (fp32, int32) buffers all the slot arrays are views of
-
-    @staticmethod
-    def from_flats(wf, wi, batch, cap):
-        """Slot arrays as views of one fp32 (n*48) and one int32 (n + batch rounded up to 4) buffer."""
-        n, b = batch * cap, batch
-        return TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
-                                wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), cap, b, (wf, wi))
-
-    def clone_static(self):
-        """Persistent copy (own storage) that `copy_from` refreshes: the double buffer of the step pipeline."""
-        wf, wi = (t.clone() for t in self.flats)
-        return TeacherKnowledge.from_flats(wf, wi, self.batch, self.cap)
-
-    def slice_static(self, j, groups):
-        """Persistent TeacherKnowledge for ONE batch out of a result computed on `groups` batches at once."""
-        b = self.batch // groups
-        n = b * self.cap
-        wf = self.flats[0].new_zeros(n * 48)
-        wi = self.flats[1].new_zeros(n + (b + 3) // 4 * 4)
-        out = TeacherKnowledge(wi[n:n + b], wf[0:n * 16].view(n, 8, 2), wf[n * 32:n * 40].view(n, 8), wi[0:n],
-                               wf[n * 16:n * 32].view(n, 8, 2), wf[n * 40:n * 48].view(n, 8), self.cap, b, (wf, wi))
-        out.copy_slice_from(self, j, groups)
-        return out
-
-    def copy_slice_from(self, big, j, groups):
-        """self (one batch) <- rows of batch j of `big` (computed on `groups` batches)."""
-        b, cap = self.batch, self.cap
-        n, N = b * cap, big.batch * big.cap
-        r0 = j * n
-        sf, bf = self.flats[0], big.flats[0]
-        for width, s_off, b_off in ((16, 0, 0), (16, n * 16, N * 16), (8, n * 32, N * 32), (8, n * 40, N * 40)):
-            sf[s_off:s_off + n * width].copy_(bf[b_off + r0 * width:b_off + (r0 + n) * width], non_blocking=True)
-        self.t_row.copy_(big.t_row[r0:r0 + n], non_blocking=True)
-        self.t_cnt.copy_(big.t_cnt[j * b:(j + 1) * b], non_blocking=True)
-        for key in ("post_kp_2d", "post_kp_cls", "post_pos_per_img"):
-            self.pop(key, None)
 
     def copy_from(self, other):
         for mine, theirs in zip(self.flats, other.flats):
@@ -229,9 +187,10 @@ class DeferredTeacher:
 
 
 def teacher_select(cls_t, reg_t, levels, batch, bbox_trans, th=0.1, positive_num=10, positive_lambda=1.0, cap=CAP,
-                   frame_wh=(640.0, 480.0), flats=None):
+                   frame_wh=(640.0, 480.0), flats=None, zeroed=False):
     """flats: optional caller-owned (fp32 n*48, int32 n + batch rounded up to 4) output buffers (the step pipeline
-    keeps them inside its hand-over block); zeroed here."""
+    keeps them inside its hand-over block); zeroed here unless the caller already did (zeroed=True: the teacher's
+    step prologue, ops.zero_many)."""
     dev = cls_t.device
     lv = make_levels(batch, levels)
     n = batch * cap
@@ -241,7 +200,8 @@ def teacher_select(cls_t, reg_t, levels, batch, bbox_trans, th=0.1, positive_num
     else:
         wf, wi = flats
         assert wf.numel() == n * 48 and wi.numel() == n + (batch + 3) // 4 * 4
-        wf.zero_(); wi.zero_()
+        if not zeroed:
+            wf.zero_(); wi.zero_()
     t_kp, t_kp_n = wf[0:n * 16].view(n, 8, 2), wf[n * 16:n * 32].view(n, 8, 2)
     t_score, t_beta = wf[n * 32:n * 40].view(n, 8), wf[n * 40:n * 48].view(n, 8)
     t_row, t_cnt = wi[0:n], wi[n:n + batch]
@@ -280,11 +240,24 @@ class KDLoss:
             raise NotImplementedError("unweighted OT (--weightedOT false) is not implemented on the HIP path")
         self.cap = cap
         self.ctx = None
+        self._ws = {}
         self.anchor_sizes, self.anchor_strides = ANCHOR_SIZES, ANCHOR_STRIDES      # configs/ape.yaml:3-4
 
-    def assign(self, levels, batch, tgt, keys=None):
+    def workspaces(self, batch, device):
+        """The per-step accumulators / slot arrays of the loss side, (fp32, int32), persistent per batch size: the
+        step prologue (PoseModuleKD._begin_step) zeroes them together with the gradient bucket."""
+        key = (batch, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            n, bp = batch * self.cap, (batch + 3) // 4 * 4
+            ws = self._ws[key] = (torch.zeros(8 + bp + n * 64, dtype=torch.float32, device=device),
+                                  torch.zeros(3 * bp + 4 + 2 * n, dtype=torch.int32, device=device))
+        return ws
+
+    def assign(self, levels, batch, tgt, keys=None, prezeroed=False):
         """SSC target assignment + the zeroed per-step workspaces.  Depends on the targets only, not on the student's
-        output: the graphed step runs it on a side stream beside the student's forward."""
+        output: the graphed step runs it on a side stream beside the student's forward.  prezeroed: the workspaces
+        are the persistent pair of workspaces(), already zeroed by the step prologue."""
         dev = tgt.mask.device
         rows = batch * sum(h * w for h, w in levels)
         cap = self.cap
@@ -297,8 +270,11 @@ class KDLoss:
         n = batch * cap
         bp = (batch + 3) // 4 * 4
         # one zero fill per dtype for every per-step accumulator / slot array of the loss side
-        wf = torch.zeros(8 + bp + n * 64, **f32)
-        wi = torch.zeros(3 * bp + 4 + 2 * n, **i32)
+        if prezeroed:
+            wf, wi = self.workspaces(batch, dev)
+        else:
+            wf = torch.zeros(8 + bp + n * 64, **f32)
+            wi = torch.zeros(3 * bp + 4 + 2 * n, **i32)
         pos_cnt = wi[0:batch]
         pos_row, pos_gt = wi[3 * bp + 4:3 * bp + 4 + n], wi[3 * bp + 4 + n:3 * bp + 4 + 2 * n]
         P = ops._ptr

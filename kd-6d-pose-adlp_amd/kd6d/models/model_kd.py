@@ -187,11 +187,18 @@ class PoseModuleKD(nn.Module):
             l_cls, l_reg, l_kd = _StepFn.apply(self._anchor, losses, self)
             return None, {"loss_cls": l_cls, "loss_reg": l_reg, "loss_kd": l_kd}
         if is_teacher:
-            cls, reg = net.forward(x)
+            # caller-owned output buffers (GraphedKDStep): cleared together with the statistics arena in one launch
+            flats = getattr(self, "_teacher_flats", None)
+            if flats is not None and flats[0].numel() != B * kd_losses.CAP * 48:
+                flats = None                  # another batch size than the one the buffers were made for
+            pre = flats is not None and net.scratch_region() is not None
+            if pre:
+                ops.zero_many([net.scratch_region(), flats[0], flats[1]])
+            cls, reg = net.forward(x, scratch_zeroed=pre)
             tgt = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, net.device)
             tk = kd_losses.teacher_select(cls, reg, net.levels, B, tgt.bbox_trans, self.inference_th,
                                           self.positive_num, self.positive_lambda, frame_wh=tgt.frame_wh,
-                                          flats=getattr(self, "_teacher_flats", None))
+                                          flats=flats, zeroed=pre)
             if self.teacher_pnp_gate:
                 self._apply_pnp_gate(tk, cls, tgt)
             return tk
@@ -225,8 +232,30 @@ class PoseModuleKD(nn.Module):
             keep.append(1 if ok else 0)
         tk.t_cnt.mul_(torch.tensor(keep, dtype=tk.t_cnt.dtype, device=tk.t_cnt.device))
 
-    def _forward_losses(self, x, targets, pred_t):
-        """Student forward + the three loss sums -> fp32[3] device tensor {cls, reg, kd} (unweighted)."""
+    def _begin_step(self, x):
+        """Step prologue of the fused training step: ONE launch zeroes the gradient bucket (the reference's
+        optimizer.zero_grad(), train_kd.py:104), the statistics arena, the dense head gradient and the loss-side slot
+        arrays, and counts the step in num_batches_tracked.  Returns True when everything could be covered (the level
+        grid of this input shape is known from an earlier forward); otherwise only the bucket and the counters are
+        done here and the forward / loss code zero their own buffers as in the eager path."""
+        net, st = self.net, self.net.store
+        st.ensure_grads()
+        first = _get_shell(self, ["head", "cls_logits"])._parameters["weight"]
+        if first.grad is None:
+            self._bind_grads()
+        B = x.shape[0]
+        known = (net.levels is not None and net.batch == B and net.in_hw == tuple(x.shape[-2:])
+                 and net.scratch_region() is not None and getattr(self, "_debug_keys", None) is None)
+        regions = [st.grads]
+        if known:
+            wf, wi = self.loss_evaluator.workspaces(B, net.device)
+            regions += [net.scratch_region(), net.buf("dreg", (net.rows, net.pose_pred.cout_p)), wf, wi]
+        ops.zero_many(regions, counter=self._nbt if known else None)     # else: _forward_losses counts the step
+        return known
+
+    def _forward_losses(self, x, targets, pred_t, prezeroed=False):
+        """Student forward + the three loss sums -> fp32[3] device tensor {cls, reg, kd} (unweighted).
+        prezeroed: _begin_step() covered the scratch arena, the loss workspaces and the step counters."""
         net = self.net
         B = x.shape[0]
         st = net.store
@@ -241,8 +270,8 @@ class PoseModuleKD(nn.Module):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pre = self.loss_evaluator.assign(net.levels, B, tgt, keys)
-        cls, reg = net.forward(x)
+                pre = self.loss_evaluator.assign(net.levels, B, tgt, keys, prezeroed=prezeroed)
+        cls, reg = net.forward(x, scratch_zeroed=prezeroed)
         if pre is not None:
             torch.cuda.current_stream().wait_stream(side)
         ops.mark("student.fwd.end")
@@ -254,23 +283,26 @@ class PoseModuleKD(nn.Module):
         losses = self.loss_evaluator.forward(cls, reg, net.levels, B, tgt, teacher, keys=keys,
                                              seg_scale=st.storage(net.scales), pre=pre)
         ops.mark("student.loss.end")
-        self._nbt += 1
+        if not prezeroed:
+            self._nbt += 1
         return losses
 
     def step_losses(self, images, targets, pred_t, weights):
         """forward + backward of d(sum_i weights[i] * loss_i) without the autograd detour (the ~16 one-element
         torch kernels that `(l_cls * w + ...).backward()` puts between the loss and the reverse sweep).
-        weights: fp32[3] device tensor.  Returns the fp32[3] loss tensor; gradients land in the flat bucket."""
+        weights: fp32[3] device tensor.  Returns the fp32[3] loss tensor (static storage: the next call overwrites
+        it).  The call opens with its own zero_grad() -- the gradients of THIS batch land in the flat bucket."""
         if not self.training:
             raise RuntimeError("step_losses() is the training step")
         x = images.tensors if hasattr(images, "tensors") else images
         if x.device != self.net.device:
             raise RuntimeError("images are on %s but the model is on %s" % (x.device, self.net.device))
-        losses = self._forward_losses(x, targets, pred_t)
-        self._run_backward(weights)
+        pre = self._begin_step(x)
+        losses = self._forward_losses(x, targets, pred_t, prezeroed=pre)
+        self._run_backward(weights, dreg_zeroed=pre)
         return losses
 
-    def _run_backward(self, weights):
+    def _run_backward(self, weights, dreg_zeroed=False):
         net, st = self.net, self.net.store
         first = _get_shell(self, ["head", "cls_logits"])._parameters["weight"]
         if first.grad is None:
@@ -278,7 +310,8 @@ class PoseModuleKD(nn.Module):
         rows = net.rows
         dcls = net.buf("dcls", (rows, 16))
         dreg = net.buf("dreg", (rows, self.net.pose_pred.cout_p))
-        dreg.zero_()
+        if not dreg_zeroed:
+            dreg.zero_()
         self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.storage(net.scales, "grads"))
         ops.mark("student.bwd.start")
         net.backward(dcls, dreg)

@@ -177,6 +177,25 @@ class option:
         return False
 
 
+def zero_many(tensors, counter=None):
+    """kd6d_zero_regions: zero every tensor of `tensors` (contiguous device tensors, None entries skipped) and add 1
+    to each element of the int64 tensor `counter`, as one launch on the current stream."""
+    lst = _lib.ZeroList()
+    n = 0
+    for t in tensors:
+        if t is None or t.numel() == 0:
+            continue
+        assert t.is_contiguous() and n < _lib.MAX_ZERO
+        lst.ptr[n] = t.data_ptr()
+        lst.bytes[n] = t.numel() * t.element_size()
+        n += 1
+    lst.n = n
+    if counter is not None:
+        assert counter.dtype == torch.int64 and counter.is_contiguous()
+    check(lib.kd6d_zero_regions(ctypes.byref(lst), _ptr(counter) if counter is not None else None,
+                                counter.numel() if counter is not None else 0, _stream()), "kd6d_zero_regions")
+
+
 def device_cu_count():
     n = lib.kd6d_device_cu_count()
     if n <= 0:

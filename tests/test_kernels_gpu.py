@@ -922,3 +922,30 @@ def test_wgrad_group_matches_torch(gpu_device, B, C, levels, n_wg):
         if db is not None:
             torch.testing.assert_close(db.cpu().double() - 0.5, ref_b, rtol=2e-4,
                                        atol=2e-4 * max(float(ref_b.abs().max()), 1.0))
+
+
+def test_zero_regions_step_prologue(gpu_device):
+    """kd6d_zero_regions: several regions of different dtypes and ragged sizes (a partial last 16-B granule, a
+    4-byte region, an empty entry) are cleared by one launch, nothing beyond a region's end is touched, and the int64
+    counters go up by one."""
+    ops = _ops()
+    dev = gpu_device
+    sizes = [(torch.float32, 1 << 20), (torch.float32, 4099), (torch.bfloat16, 2 * 7 + 16 * 5), (torch.int32, 1),
+             (torch.float32, 0), (torch.int32, 37)]
+    guards, views = [], []
+    for dt, n in sizes:
+        big = torch.full((n + 64,), 3, dtype=dt, device=dev)      # 32 guard elements either side (16-B aligned start)
+        guards.append(big)
+        views.append(big[32:32 + n])
+    counter = torch.arange(11, dtype=torch.int64, device=dev)
+    ops.zero_many(views + [None], counter=counter)
+    torch.cuda.synchronize()
+    for (dt, n), big in zip(sizes, guards):
+        assert float(big[32:32 + n].float().abs().sum()) == 0.0
+        assert bool((big[:32] == 3).all()) and bool((big[32 + n:] == 3).all()), (dt, n)
+    assert counter.tolist() == list(range(1, 12))
+    ops.zero_many([], counter=counter)
+    torch.cuda.synchronize()
+    assert counter.tolist() == list(range(2, 13))
+    with pytest.raises(RuntimeError, match="16-B aligned"):
+        ops.zero_many([guards[0][1:9]])
