@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--rccl-single-rank", action="store_true",
                    help="under `torch.distributed.run --nproc-per-node 1`: run the N > 1 code path (RCCL communicator, "
                         "the all-reduce between the two graphs, barriers) on one GPU")
+    p.add_argument("--opt", action="append", default=[],
+                   help="kernel-selection option name=value (kd6d_set_option, include/kd6d.h): tuning aid for A/B runs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--no-pipeline", action="store_true",
@@ -130,6 +132,8 @@ def main():
     from kd6d import backbone as BB, ops
     from kd6d.kd_losses import PackedTargets
     from kd6d.libs import distributed as D
+    for kv in args.opt:
+        ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     from kd6d.models.model_kd import PoseModuleKD
     from kd6d.optim import FusedClipAdamW
     from kd6d.synthetic import make_batch

@@ -155,7 +155,9 @@ int kd6d_device_cu_count(void);
 /* Kernel-selection options.  The dispatch rules inside the library are measured defaults; the parity tests and the
  * per-layer benches pin one kernel family for a call through this table (process-wide, set between launches by the
  * launching thread).  The product path sets none of them.  Names and values:
- *   conv.halo      -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64
+ *   conv.halo      -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64,
+ *                  11-15 the two-workgroups-per-CU twins (maps <= 32 wide): 128x128 on 4 / 8 waves, 128x64, 64x64, 128x32
+ *   conv.halo_pairing  1 | 0 keep the one-workgroup-per-CU halo tiles on maps <= 32 wide
  *   conv.smallc    -1 auto | 0 off | 1 the resident-patch kernel also below 2^17 pixels
  *   conv.splitk    -1 auto | 0 off | tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
  *   conv.tile      -1 auto | 0 register-staged kernel | 1 128x128, 2 128x64, 3 64x64 (LDS-DMA kernel)

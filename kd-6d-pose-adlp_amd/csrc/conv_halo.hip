@@ -22,16 +22,23 @@ namespace {
 // and k-step), the next chunk's patch double-buffered behind the current one; counted vmcnt,
 // one raw s_barrier per k-step.  Levels of a multi-level (head) launch may share a tile.
 // ---------------------------------------------------------------------------
-template <int BP, int BC, int WP, int WC, int MODE>
+//
+// HMAX: largest halo (level width + 1) the LDS patch is sized for, 65 or 33.  PDB: the next chunk's patch is
+// double-buffered behind the current one; without it the workgroup stops at a chunk boundary until the new patch
+// has landed -- in exchange a 128x128 tile fits 76 KB of LDS, so TWO workgroups (of this or of another stream's
+// launch) share a CU and one's prologue, chunk stalls and epilogue run under the other's k-loop.
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
 __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int total_rows, int bid, int nwg) {
   using T = bf16_t;
   constexpr int NW = WP * WC;
   constexpr int PI = BP / WP / 16;
   constexpr int CI = BC / WC / 16;
-  constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;   // 8-row groups of a patch (+1: the zero row lives in the last)
+  constexpr int PSLOT = (BP + 2 * HMAX + 7) / 8 + 1; // 8-row groups of a patch (+1: the zero row lives in the last)
   constexpr int PL = (PSLOT + NW - 1) / NW;          // patch LDS-DMA instructions per wave per chunk
-  constexpr int PATCH_BYTES = PL * NW * 1024;
-  constexpr int ZERO_ROW = PL * NW * 8 - 1;          // never a real patch row: always filled from the zero page
+  // double-buffered: every wave issues the same PL pieces per chunk (the counted vmcnt waits rely on it), slots past
+  // PSLOT are padding; single buffer: only the PSLOT slots exist (its loads are followed by vmcnt(0))
+  constexpr int PATCH_BYTES = (PDB ? PL * NW : PSLOT) * 1024;
+  constexpr int ZERO_ROW = (PDB ? PL * NW : PSLOT) * 8 - 1;   // never a real patch row: always filled from the zero page
   constexpr int WL = BC / 8 / NW;                    // weight LDS-DMA instructions per wave per k-step
   constexpr int WSTAGE = BC * 128;
   static_assert(BC % (8 * NW) == 0 && PI >= 1 && CI >= 1, "tile shape");
@@ -39,7 +46,7 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wring = smem;                      // 3 weight stages first: their fragment reads use immediate offsets
-  char* const pbuf = smem + 3 * WSTAGE;          // 2 patch buffers
+  char* const pbuf = smem + 3 * WSTAGE;          // 2 patch buffers (PDB) or 1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,6 +123,7 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       const int slot = wave + NW * i;
+      if (!PDB && slot >= PSLOT) continue;
       const int prow = 8 * slot + lrow;
       const int row = patch_lo + prow;
       const void* g = zero;
@@ -151,7 +159,7 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
   // ~100+ cycles of issue; straight behind the barrier both waves of a SIMD paid that with an empty matrix pipe).
   Frag<T> ga[CI], gb[PI];
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const bool more_patch = chunk + 1 < nchunk;
+    const bool more_patch = PDB && chunk + 1 < nchunk;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kt = chunk * 9 + tap;
@@ -201,12 +209,20 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
         issue_patch((chunk + 1) & 1, chunk + 1, tap * PPT, (tap + 1) * PPT < PL ? (tap + 1) * PPT : PL);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the next chunk reads the other patch buffer
-    const int flip = (chunk & 1) ? -PATCH_BYTES : PATCH_BYTES;
+    if constexpr (PDB) {     // the next chunk reads the other patch buffer
+      const int flip = (chunk & 1) ? -PATCH_BYTES : PATCH_BYTES;
 #pragma unroll
-    for (int q = 0; q < PI; ++q)
+      for (int q = 0; q < PI; ++q)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) pa[q][tap] += flip;
+        for (int tap = 0; tap < 9; ++tap) pa[q][tap] += flip;
+    } else if (chunk + 1 < nchunk) {
+      // single buffer: every wave's fragment reads of this chunk are in registers (lgkmcnt 0) before the patch is
+      // overwritten; the new one is complete (vmcnt 0; the next k-step's barrier publishes it) before it is read
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_patch(0, chunk + 1, 0, PL);
+      wait_vmcnt<0>();
+    }
   }
 #pragma unroll
   for (int c = 0; c < CI; ++c)
@@ -216,20 +232,22 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
   conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
 }
 
-template <int BP, int BC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
-  halo_tile<BP, BC, WP, WC, MODE>(p, halo, total_rows, blockIdx.x, gridDim.x);
+// second launch bound = waves per SIMD the register budget has to leave room for: the single-buffer variants are
+// built to run two workgroups per CU
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+__global__ __launch_bounds__(WP* WC * 64, PDB ? 1 : WP * WC / 2) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
+  halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB>(p, halo, total_rows, blockIdx.x, gridDim.x);
 }
 
 // Two convolutions of identical geometry (the cls and the pose tower layer of the head: different tensors and
 // weights, same shapes) as ONE launch: workgroups [0, tiles_a) run `pa`, the rest `pb`.  A student tower layer
 // alone is 170 tiles of 128x128 on 256 CUs, one 128-KB workgroup per CU -- a second stream cannot use the idle
 // third; as a pair the two layers are 228 tiles of 192x128, one full round for both.
-template <int BP, int BC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(WP* WC * 64) void conv3x3_halo_pair_kernel(const ConvParams pa, const ConvParams pb,
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+__global__ __launch_bounds__(WP* WC * 64, PDB ? 1 : WP * WC / 2) void conv3x3_halo_pair_kernel(const ConvParams pa, const ConvParams pb,
                                                                         int halo, int total_rows, int tiles_a) {
-  if ((int)blockIdx.x < tiles_a) halo_tile<BP, BC, WP, WC, MODE>(pa, halo, total_rows, blockIdx.x, tiles_a);
-  else halo_tile<BP, BC, WP, WC, MODE>(pb, halo, total_rows, blockIdx.x - tiles_a, gridDim.x - tiles_a);
+  if ((int)blockIdx.x < tiles_a) halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB>(pa, halo, total_rows, blockIdx.x, tiles_a);
+  else halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB>(pb, halo, total_rows, blockIdx.x - tiles_a, gridDim.x - tiles_a);
 }
 
 // kd6d_conv2d_pair_begin / _end: between the two calls, halo-kernel launches are recorded instead of issued; two
@@ -248,18 +266,18 @@ struct PairState {
 };
 thread_local PairState g_pair;
 
-template <int BP, int BC, int WP, int WC, int MODE>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX, bool PDB>
 size_t halo_lds() {
   constexpr int NW = WP * WC;
-  constexpr int PSLOT = (BP + 2 * 65 + 7) / 8 + 1;
+  constexpr int PSLOT = (BP + 2 * HMAX + 7) / 8 + 1;
   constexpr int PL = (PSLOT + NW - 1) / NW;
-  return (size_t)2 * PL * NW * 1024 + (size_t)3 * BC * 128;
+  return (PDB ? (size_t)2 * PL * NW : (size_t)PSLOT) * 1024 + (size_t)3 * BC * 128;
 }
 
-template <int BP, int BC, int WP, int WC, int MODE>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
 void halo_issue_single(const HaloRecord& r) {
-  const size_t lds = halo_lds<BP, BC, WP, WC, MODE>();
-  auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE>;
+  const size_t lds = halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>();
+  auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE, HMAX, PDB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -269,10 +287,10 @@ void halo_issue_single(const HaloRecord& r) {
   hipLaunchKernelGGL(kern, dim3(r.tiles), dim3(WP * WC * 64), lds, r.st, r.q, r.halo, r.total_rows);
 }
 
-template <int BP, int BC, int WP, int WC, int MODE>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
 void halo_issue_pair(const HaloRecord& a, const HaloRecord& b) {
-  const size_t lds = halo_lds<BP, BC, WP, WC, MODE>();
-  auto kern = conv3x3_halo_pair_kernel<BP, BC, WP, WC, MODE>;
+  const size_t lds = halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>();
+  auto kern = conv3x3_halo_pair_kernel<BP, BC, WP, WC, MODE, HMAX, PDB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -283,7 +301,7 @@ void halo_issue_pair(const HaloRecord& a, const HaloRecord& b) {
                      a.tiles);
 }
 
-template <int BP, int BC, int WP, int WC, int MODE>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
 void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
   HaloRecord r;
   r.q = p;
@@ -291,8 +309,8 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(r.q, ptiles, BP, BC);
   r.halo = halo; r.total_rows = total_rows; r.tiles = ptiles * r.q.n_ctiles; r.st = st;
-  r.single = &halo_issue_single<BP, BC, WP, WC, MODE>;
-  r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE>;
+  r.single = &halo_issue_single<BP, BC, WP, WC, MODE, HMAX, PDB>;
+  r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE, HMAX, PDB>;
   if (g_pair.active && g_pair.count < 2) { g_pair.rec[g_pair.count++] = r; return; }
   r.single(r);
 }
@@ -338,8 +356,23 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   else if (pf * ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 150) pick = 1;
   else if (pt128 * ((p.N + 127) / 128) >= 160) pick = 3;
   else if (pt128 * ((p.N + 63) / 64) >= 64) pick = 4;
-  if (force > 0) pick = force;
+  // maps up to 32 wide (halo <= 33): the single-patch-buffer twin of the picked tile, 38-74 KB of LDS instead of
+  // 104-144, so that two workgroups -- of this launch or of the other stream's -- share a CU.  Alone on the device a
+  // twin is as fast as its original or up to 40 % slower (chunk-boundary stalls, no partner to cover them); inside
+  // the step the pairs give +4 % (4889-4918 -> 5097 images/s, interleaved runs; profiles/r02_halo_pairing.md)
+  if (kd6d_opt(KD6D_OPT_CONV_HALO_PAIRING) != 0 && halo <= 33) {
+    if (pick == 3 || pick == 6) pick = 12;
+    else if (pick == 4) pick = 13;
+    else if (pick == 9) pick = 14;
+    else if (pick == 5) pick = 15;
+  }
+  if (force > 0 && (force < 10 || halo <= 33)) pick = force;      // 11..15: the twins, maps <= 32 wide only
   if (pick == 0) return false;
+  if (pick == 11) { launch_halo<128, 128, 2, 2, MODE, 33, false>(p, halo, rows, st); return true; }
+  if (pick == 12) { launch_halo<128, 128, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }
+  if (pick == 13) { launch_halo<128, 64, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }
+  if (pick == 14) { launch_halo<64, 64, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }
+  if (pick == 15) { launch_halo<128, 32, 4, 1, MODE, 33, false>(p, halo, rows, st); return true; }
   if (pick == 1) launch_halo<256, 128, 4, 2, MODE>(p, halo, rows, st);
   else if (pick == 3) launch_halo<128, 128, 4, 2, MODE>(p, halo, rows, st);      // 8 waves on the 128x128 tile
   else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);

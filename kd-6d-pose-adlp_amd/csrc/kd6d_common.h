@@ -39,7 +39,8 @@ void kd6d_set_error(const char* fmt, ...);
 // One table instead of environment variables: the parity tests and the per-layer benches select a kernel family
 // through the C ABI, inside one process; the product path never sets any of them.
 enum Kd6dOption {
-  KD6D_OPT_CONV_HALO = 0,      // -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64
+  KD6D_OPT_CONV_HALO = 0,      // -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64,
+                               // 11-15 the two-per-CU twins: 128x128 on 4 / on 8 waves, 128x64, 64x64, 128x32
   KD6D_OPT_CONV_SMALLC,        // -1 auto | 0 off | 1 also below 2^17 pixels
   KD6D_OPT_CONV_SPLITK,        // -1 auto | 0 off | tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
   KD6D_OPT_CONV_TILE,          // -1 auto | 0 register-staged kernel | 1 128x128, 2 128x64, 3 64x64 (LDS-DMA kernel)
@@ -48,6 +49,7 @@ enum Kd6dOption {
   KD6D_OPT_BN_ONEPASS_MAX,     // largest x (16-B granules) on the one-launch BN backward
   KD6D_OPT_GN_ONEPASS,         // 1 | 0: the two-launch GN backward
   KD6D_OPT_SINKHORN_LANES,     // 1 | 0: every set on the general (one softmin after the other) path
+  KD6D_OPT_CONV_HALO_PAIRING,  // 1 | 0: maps <= 32 wide keep the double-buffered (one workgroup per CU) halo tiles
   KD6D_OPT_COUNT
 };
 long long kd6d_opt(int id);

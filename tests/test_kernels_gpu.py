@@ -369,6 +369,33 @@ def test_conv_resident_patch_kernel_on_every_small_c_case(gpu_device, dtype, cas
         test_conv_fwd_fused_statistics(gpu_device, dtype, (B, Cin, Cout, k, stride, levels, 0))
 
 
+@pytest.mark.parametrize("variant", [11, 12, 13, 14, 15])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] == 3 and c[4] == 1 and c[1] % 64 == 0
+                                  and max(w for _, w in c[5]) <= 32])
+def test_conv_halo_two_per_cu_variants(gpu_device, case, variant):
+    """The single-patch-buffer halo variants built for two workgroups per CU (option conv.halo = 11: 128x128 on 4
+    waves, 12: on 8 waves, 13: 128x64, 14: 64x64, 15: 128x32; maps up to 32 wide): forward, data gradient and the
+    fused statistics on the multi-level, N-tail and 3-chunk cases -- the chunk-boundary reload is what these exercise
+    (Cin 128, 192, 256).  The default dispatch uses them too (conv.halo_pairing = 1); the double-buffered originals
+    stay covered by the same cases with the pairing switched off."""
+    _option("conv.halo", variant)
+    test_conv_fwd_plain(gpu_device, torch.bfloat16, case)
+    test_conv_dgrad(gpu_device, torch.bfloat16, case)
+    B, Cin, Cout, k, stride, levels = case
+    if Cout % 4 == 0:
+        test_conv_fwd_fused_statistics(gpu_device, torch.bfloat16, (B, Cin, Cout, k, stride, levels, 0))
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] == 3 and c[4] == 1 and c[1] % 64 == 0])
+def test_conv_halo_one_per_cu_originals(gpu_device, case):
+    _option("conv.halo_pairing", 0)
+    test_conv_fwd_plain(gpu_device, torch.bfloat16, case)
+    test_conv_dgrad(gpu_device, torch.bfloat16, case)
+    B, Cin, Cout, k, stride, levels = case
+    if Cout % 4 == 0:
+        test_conv_fwd_fused_statistics(gpu_device, torch.bfloat16, (B, Cin, Cout, k, stride, levels, 0))
+
+
 def test_pack_dgrad_weights(gpu_device):
     ops = _ops()
     dev = gpu_device
