@@ -368,7 +368,8 @@ int kd6d_dzi_crop(const uint8_t* frames_bgr, const float* masks, int B, int H, i
  * kd6d_sumsq accumulates sum(x^2) into *out (pre-zeroed); kd6d_clip_adamw applies
  * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update
  * (torch.optim.AdamW semantics, step counted from 1) and refreshes the bf16 shadow if given.
- * hyper_dev (optional, 4 floats on the device: lr, 1-beta1^t, sqrt(1-beta2^t), pad) overrides lr/step:
+ * hyper_dev (optional, 4 floats on the device: lr, 1-beta1^t, sqrt(1-beta2^t), and a fourth that kd6d_set_hyper
+ * sets to 0 -- the host keeps its gradient-norm accumulator there, cleared without a launch of its own) overrides lr/step:
  * it lets the launch sit inside a captured hipGraph while the OneCycle schedule of
  * libs/train_libs.py:120 keeps advancing on the host; kd6d_set_hyper writes it (values travel in
  * the kernel arguments, so the host may run ahead of the device). */

@@ -301,6 +301,76 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
       }
     }
   }
+  // bf16 result, N % 8 == 0: lanes (fq, fq ^ 1) swap one of their two 4-channel groups of a channel-tile pair, so that
+  // each holds 8 consecutive channels and stores 16 B (16 rows x 64 B per wave instruction instead of 16 x 32 B, half
+  // the store instructions -- the epilogue of these launches is store-issue-bound); the residual is then read 16 B
+  // wide as well.  Arithmetic and rounding are those of the 4-channel path below.
+  if constexpr (sizeof(T) == 2 && HOIST && (CI % 2 == 0)) {
+    if (!p.out_f32 && (p.N & 7) == 0 && !(p.stats && p.residual)) {
+      const bool odd = fq & 1;
+      const int partner = (lane ^ 16) << 2;
+#pragma unroll
+      for (int q = 0; q < PI; ++q) {
+        const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+        const bool row_ok = m < p.M;
+        int drow = m, sg = 0;
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s) {
+          if (s < p.nseg && m >= p.seg[s].m_begin) {
+            drow = p.seg[s].dst_row0 + (m - p.seg[s].m_begin);
+            sg = s;
+          }
+        }
+        float sscale = 1.f;
+        if (p.seg_scale && row_ok) sscale = p.seg_scale[sg];
+#pragma unroll
+        for (int cp = 0; cp < CI / 2; ++cp) {
+          f32x4_t va0, va1;       // this lane's 4 channels of tiles 2cp and 2cp + 1
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t0 = (acc[2 * cp][q][r] * hsc[2 * cp][r] + hsh[2 * cp][r]) * sscale;
+            float t1 = (acc[2 * cp + 1][q][r] * hsc[2 * cp + 1][r] + hsh[2 * cp + 1][r]) * sscale;
+            if (p.act == KD6D_ACT_LEAKY) {
+              t0 = t0 > 0.f ? t0 : 0.1f * t0;
+              t1 = t1 > 0.f ? t1 : 0.1f * t1;
+            } else if (p.act == KD6D_ACT_RELU) {
+              t0 = fmaxf(t0, 0.f);
+              t1 = fmaxf(t1, 0.f);
+            }
+            va0[r] = t0;
+            va1[r] = t1;
+          }
+          if (p.stats) {          // statistics of the stored values, in this lane's ORIGINAL channels (no residual here)
+            acc[2 * cp][q] = va0;
+            acc[2 * cp + 1][q] = va1;
+          }
+          // even fq keeps tile 2cp and takes the partner's (fq + 1) group of it; odd fq keeps tile 2cp + 1
+          const f32x4_t send = odd ? va0 : va1;
+          f32x4_t got;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            got[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(send[r])));
+          f32x4_t lo = odd ? got : va0, hi = odd ? va1 : got;
+          const int n = n0 + wc * (BC / WC) + (2 * cp + (odd ? 1 : 0)) * 16 + (fq & ~1) * 4;
+          if (!row_ok || n >= p.N) continue;
+          const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
+          if (p.residual) {
+            const u32x4_t r8 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.residual) + o);
+            lo[0] += __uint_as_float(r8.x << 16); lo[1] += __uint_as_float(r8.x & 0xffff0000u);
+            lo[2] += __uint_as_float(r8.y << 16); lo[3] += __uint_as_float(r8.y & 0xffff0000u);
+            hi[0] += __uint_as_float(r8.z << 16); hi[1] += __uint_as_float(r8.z & 0xffff0000u);
+            hi[2] += __uint_as_float(r8.w << 16); hi[3] += __uint_as_float(r8.w & 0xffff0000u);
+          }
+          u32x4_t pk;
+          pk.x = pack_bf16x2(lo[0], lo[1]); pk.y = pack_bf16x2(lo[2], lo[3]);
+          pk.z = pack_bf16x2(hi[0], hi[1]); pk.w = pack_bf16x2(hi[2], hi[3]);
+          *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
+        }
+      }
+      if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
+      return;
+    }
+  }
 #pragma unroll
   for (int q = 0; q < PI; ++q) {
     const int m = m0 + wp * (BP / WP) + q * 16 + fr;

@@ -20,8 +20,10 @@ class FusedClipAdamW(torch.optim.Optimizer):
         dev = st.params.device
         self.exp_avg = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
-        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)     # lr, 1-b1^t, sqrt(1-b2^t): graph-replay form
+        # lr, 1-b1^t, sqrt(1-b2^t) in graph-replay form, and the squared gradient norm accumulator: kd6d_set_hyper
+        # (advance(), before every launch) writes the three and clears the fourth in one launch
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.gnorm_sq = self.hyper[3:4]
         self.steps = 0
 
     @torch.no_grad()
@@ -30,8 +32,9 @@ class FusedClipAdamW(torch.optim.Optimizer):
         self.launch(device_schedule=False)
 
     def advance(self):
-        """Host half of a step: count it and publish (lr, bias corrections) to the device.  In graph
-        mode this runs eagerly before every replay of the captured `launch(device_schedule=True)`."""
+        """Host half of a step: count it, publish (lr, bias corrections) to the device and clear the gradient-norm
+        accumulator.  In graph mode this runs eagerly before every replay of the captured
+        `launch(device_schedule=True)`; launch() without a preceding advance() would add to the old norm."""
         g = self.param_groups[0]
         self.steps += 1
         check(lib.kd6d_set_hyper(ops._ptr(self.hyper), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
@@ -46,7 +49,6 @@ class FusedClipAdamW(torch.optim.Optimizer):
         n = st.n_train
         P = ops._ptr
         s = ops._stream()
-        self.gnorm_sq.zero_()
         check(lib.kd6d_sumsq(P(st.grads), n, P(self.gnorm_sq), s), "kd6d_sumsq")
         shadow = st.ensure_shadow() if self.net.dtype == torch.bfloat16 else None
         check(lib.kd6d_clip_adamw(P(st.params), P(st.grads), P(self.exp_avg), P(self.exp_avg_sq), n, P(self.gnorm_sq),
