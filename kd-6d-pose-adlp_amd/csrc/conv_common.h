@@ -277,7 +277,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
 
 // Epilogue shared by the register-staged and the LDS-DMA kernels: lane owns pixel (lane&15),
 // channels (lane>>4)*4 .. +3 of every 16x16 accumulator tile.
-template <typename T, int BP, int BC, int WP, int WC>
+template <typename T, int BP, int BC, int WP, int WC, bool WIDE = true>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
                                               int m0, int n0, int wp, int wc, int lane, float* smem_f32) {
   constexpr int PI = BP / WP / 16;
@@ -305,7 +305,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
   // each holds 8 consecutive channels and stores 16 B (16 rows x 64 B per wave instruction instead of 16 x 32 B, half
   // the store instructions -- the epilogue of these launches is store-issue-bound); the residual is then read 16 B
   // wide as well.  Arithmetic and rounding are those of the 4-channel path below.
-  if constexpr (sizeof(T) == 2 && HOIST && (CI % 2 == 0)) {
+  // (WIDE = false: the resident-patch kernel, VALU-bound already -- measured 31 -> 36 us on the teacher's stage-1 3x3)
+  if constexpr (WIDE && sizeof(T) == 2 && HOIST && (CI % 2 == 0)) {
     if (!p.out_f32 && (p.N & 7) == 0 && !(p.stats && p.residual)) {
       const bool odd = fq & 1;
       const int partner = (lane ^ 16) << 2;

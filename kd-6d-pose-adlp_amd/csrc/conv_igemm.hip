@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_kernel(const ConvParams p,
 #pragma unroll
       for (int q = 0; q < PI; ++q) mma(fa[c], fb[q], acc[c][q]);
   }
-  conv_epilogue<T, BP, BC, 4, 1>(p, acc, m0, n0, wave, 0, lane, reinterpret_cast<float*>(smem));
+  conv_epilogue<T, BP, BC, 4, 1, false>(p, acc, m0, n0, wave, 0, lane, reinterpret_cast<float*>(smem));
 }
 
 // ---------------------------------------------------------------------------
