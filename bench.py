@@ -271,7 +271,7 @@ def main():
         peak = PEAK_BF16 if args.precision == "bf16" else PEAK_F32
         achieved = tot_flop / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(HERE, "profiles", "r01_conv_hbm_traffic.json")
+        tpath = os.path.join(HERE, "profiles", "r02_conv_hbm_traffic.json")
         if os.path.exists(tpath) and args.student == "darknet_tiny_h" and not full and B == 16 and args.precision == "bf16":
             # HBM bytes of the conv family per step from rocprofv3 PMC passes (tools/pmc_traffic.sh, FETCH_SIZE x2
             # per the gfx950 correction + WRITE_SIZE), committed with the profile it was taken from
@@ -289,7 +289,7 @@ def main():
                 "achieved": wall_tflops / 1e12 if wall_tflops else achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": (wall_tflops if wall_tflops else achieved) / peak,
                 "flop_per_step": flop_img * B if flop_img else tot_flop / n_instr,
-                "traffic": traffic, "traffic_unit": "HBM bytes per step, conv family (PMC, profiles/r01_conv_hbm_traffic.json)",
+                "traffic": traffic, "traffic_unit": "HBM bytes per step, conv family (PMC, profiles/r02_conv_hbm_traffic.json)",
                 "eager_launch_events": {
                     "note": "HIP events around every conv launch of %d eagerly launched single-stream steps after the "
                             "timed region; NOT the timed schedule" % n_instr,
