@@ -67,6 +67,7 @@ class GraphedKDStep:
         self.t_cur = None                                  # pipeline: teacher cells of `images`
         self._blocks = None                                # pipeline: [current, next] hand-over blocks
         self.pending = False
+        self.primed = False                                # pipeline: the teacher has seen a batch the student has not
 
     # ---- the body the reference's loop runs per iteration (train_kd.py:104-137) ----------
     def _student_step(self, pred_t):
@@ -235,13 +236,19 @@ class GraphedKDStep:
             if self.g_step is None:
                 self._capture()
             return self._replay()
-        if self.t_cur is None:                  # priming call: teacher only, the student starts next call
+        if not self.primed:                     # priming call: teacher only, the student starts next call
+            flats = getattr(self.teacher, "_teacher_flats", None)
+            self.teacher._teacher_flats = None  # (eager call: fresh output buffers, not the captured step's)
             with torch.no_grad():
                 pred = self.teacher(self.images_nxt, targets=self.tgt_nxt, is_teacher=True, cfg_kd=self.cfg_kd)
-            self.t_cur = pred.clone_static()
+            self.teacher._teacher_flats = flats
+            if self.t_cur is None:
+                self.t_cur = pred.clone_static()
+            else:                               # a new pipeline after flush(): the captured step's buffers stay
+                self.t_cur.copy_from(pred)
             self.images.tensors.copy_(self.images_nxt.tensors)
             self.tgt.copy_from(self.tgt_nxt)
-            self.pending = True
+            self.primed = self.pending = True
             return None
         if self.g_step is None:
             self._capture()
@@ -250,9 +257,11 @@ class GraphedKDStep:
 
     def flush(self):
         """pipeline=True: train on the batch that is still waiting for its student step."""
-        if not (self.pipeline and self.pending and self.t_cur is not None):
+        if not (self.pipeline and self.pending and self.primed):
             return None
         if self.g_step is None:
             self._capture()
         self.pending = False
-        return self._replay()      # the teacher re-reads the same (last) batch: harmless, results unused
+        out = self._replay()       # the teacher re-reads the same (last) batch: harmless, results unused
+        self.primed = False        # a later call starts a new pipeline (teacher only) instead of repeating this batch
+        return out

@@ -370,6 +370,49 @@ def test_graph_replay_matches_eager_steps(gpu_device, precision):
     assert abs(np.abs(p_p - p0).mean() / d_e.mean() - 1.0) < 0.02
 
 
+def test_pipeline_restarts_after_flush(gpu_device):
+    """flush() trains on the batch that was still waiting; a call after it starts a NEW pipeline (teacher only)
+    instead of training on that batch a second time: 3 batches + flush = 3 optimiser steps, 2 more + flush = 5, and
+    the first loss of the second pipeline is the loss of ITS first batch at the weights of that moment (recomputed
+    eagerly on a copy of the student)."""
+    from kd6d.graph import GraphedKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import make_batch
+    dev = gpu_device
+    B, crop = 2, 64
+    teacher = build("darknet53", "fp32", 2, dev, [1.0] + [-6.0] * 14).eval()
+    batches = []
+    for i in range(3):
+        images, targets = make_batch(B, 20 + i, crop=crop)
+        batches.append((ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)))
+    rows = B * sum((crop // 8 // 2 ** i) ** 2 for i in range(4))
+    student = build("darknet_tiny_h", "fp32", 1, dev).train()
+    student._debug_keys = torch.rand(rows, generator=torch.Generator().manual_seed(3)).to(dev)
+    opt = FusedClipAdamW(student, lr=1e-4)
+    gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=True)
+    assert gs(*batches[0]) is None
+    gs(*batches[1]); gs(*batches[2])
+    gs.flush()
+    assert opt.steps == 3 and gs.flush() is None
+    assert gs(*batches[1]) is None and opt.steps == 3          # new pipeline: teacher only
+    # what the next student step must report: the losses of batches[1] at the current weights, computed eagerly on a copy
+    twin = build("darknet_tiny_h", "fp32", 1, dev).train()
+    twin.load_state_dict(student.state_dict())
+    twin._debug_keys = student._debug_keys
+    with torch.no_grad():
+        pred_t = teacher(batches[1][0], targets=batches[1][1], is_teacher=True)
+    _, want = twin(batches[1][0], targets=batches[1][1], pred_t=pred_t)
+    want = [float(want[k]) for k in ("loss_cls", "loss_reg", "loss_kd")]
+    ld = gs(*batches[0])                                       # student step on batches[1]
+    got = [float(ld[k]) for k in ("loss_cls", "loss_reg", "loss_kd")]
+    gs.flush()
+    assert opt.steps == 5
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    assert got[2] > 0, "the KD term must be active in this test"
+
+
 def test_eval_between_graph_replays_sees_current_weights(gpu_device):
     """A replayed optimiser graph changes the weights without passing through Python: the eval-mode BatchNorm
     scale/shift cached by the previous validation must not survive it (every VAL_FREQ steps train_kd.py validates
