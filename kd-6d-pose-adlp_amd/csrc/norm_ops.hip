@@ -1321,6 +1321,16 @@ __global__ __launch_bounds__(kThreads) void image_to_nhwc_kernel(const float* __
     const long long hw = (long long)H * W;
     const int b = (int)(p / hw);
     const long long r = p - (long long)b * hw;
+    if (sizeof(T) == 2 && Cpad == 8) {      // the step's case: one 16-byte store per pixel instead of eight 2-byte ones
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = c < Cimg ? img[((long long)b * Cimg + c) * hw + r] : 0.f;
+      u32x4_t g;
+      g.x = pack_bf16x2(v[0], v[1]); g.y = pack_bf16x2(v[2], v[3]);
+      g.z = pack_bf16x2(v[4], v[5]); g.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<u32x4_t*>(out + p * 8) = g;
+      continue;
+    }
     for (int c = 0; c < Cpad; ++c) {
       const float v = c < Cimg ? img[((long long)b * Cimg + c) * hw + r] : 0.f;
       out[p * Cpad + c] = from_f32<T>(v);

@@ -245,7 +245,7 @@ class PoseModuleKD(nn.Module):
             self._bind_grads()
         B = x.shape[0]
         known = (net.levels is not None and net.batch == B and net.in_hw == tuple(x.shape[-2:])
-                 and net.scratch_region() is not None and getattr(self, "_debug_keys", None) is None)
+                 and net.scratch_region() is not None)
         regions = [st.grads]
         if known:
             wf, wi = self.loss_evaluator.workspaces(B, net.device)
