@@ -355,6 +355,9 @@ class PoseNet:
         # (csrc/conv_wgrad_group.hip); created on first use, bf16 only.  wgrad_group_wgs: workgroups of that launch
         # (0 = one per two CUs).  Measured on the step (images/s, 64 / 128 / 256 workgroups): pipelined 4831 / 4828 /
         # 4788, strictly sequential 4050 / 4164 / 4241 -- GraphedKDStep asks for one per CU in sequential mode
+        # set by GraphedKDStep around its own calls only: the packed NHWC input to use instead of converting `images`
+        # (nhwc_in), or where to put the conversion (nhwc_out)
+        self.nhwc_in = self.nhwc_out = None
         self.wgrad_group = None
         self.grouping = False          # True while the reverse sweep is inside the section whose dW are collected
         self.use_wgrad_group = True
@@ -613,7 +616,13 @@ class PoseNet:
         if self.scratch_buf is not None and not scratch_zeroed:
             # one memset per step: every atomically accumulated statistic lives here (only the part in use)
             self.scratch_buf[:max(self._scratch_size, 8)].zero_()
-        x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=self.buf("input", (B * H * W, 8)))
+        if self.nhwc_in is not None:        # GraphedKDStep: the frozen teacher converted this batch one replay earlier
+            x = self.nhwc_in
+            assert x.shape == (B * H * W, 8) and x.dtype == self.dtype
+        else:
+            out = self.nhwc_out if self.nhwc_out is not None else self.buf("input", (B * H * W, 8))
+            assert out.shape == (B * H * W, 8) and out.dtype == self.dtype
+            x = ops.image_to_nhwc(images.contiguous(), self.dtype, 8, out=out)
         feats = self._backbone53(x, B, [(H, W)]) if self.arch == "darknet53" else self._backbone_tiny(x, B, [(H, W)])
         ops.mark("%s.fwd.backbone.end" % ("teacher" if not self.training else "student"))
         oc = self.out_channel

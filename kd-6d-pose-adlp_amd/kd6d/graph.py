@@ -66,6 +66,7 @@ class GraphedKDStep:
         self.images_nxt = self.tgt_nxt = None              # pipeline: the batch the teacher looks at
         self.t_cur = None                                  # pipeline: teacher cells of `images`
         self._blocks = None                                # pipeline: [current, next] hand-over blocks
+        self._nhwc = None                                  # pipeline: (current, next) packed NHWC inputs inside them
         self.pending = False
         self.primed = False                                # pipeline: the teacher has seen a batch the student has not
 
@@ -74,10 +75,23 @@ class GraphedKDStep:
         if self._w is None:
             self._w = torch.tensor([self.w_cls, self.w_reg, self.w_kd], dtype=torch.float32,
                                    device=self.student.net.device)
-        losses = self.student.step_losses(self.images, self.tgt, pred_t, self._w)
+        snet = self.student.net
+        snet.nhwc_in = self._nhwc[0] if self._nhwc is not None else None
+        try:
+            losses = self.student.step_losses(self.images, self.tgt, pred_t, self._w)
+        finally:
+            snet.nhwc_in = None
         return {"loss_cls": losses[0], "loss_reg": losses[1], "loss_kd": losses[2]}
 
     def _teacher(self, images, tgt):
+        tnet = self.teacher.net
+        tnet.nhwc_out = self._nhwc[1] if (self._nhwc is not None and images is self.images_nxt) else None
+        try:
+            return self._teacher_launch(images, tgt)
+        finally:
+            tnet.nhwc_out = None
+
+    def _teacher_launch(self, images, tgt):
         with torch.no_grad():
             if self.teacher_stream is None:
                 return self.teacher(images, targets=tgt, is_teacher=True, cfg_kd=self.cfg_kd)
@@ -117,7 +131,12 @@ class GraphedKDStep:
         layout, so that the hand-over at the end of a step is one device copy instead of six."""
         from .kd_losses import TeacherKnowledge
         dev = self.images.tensors.device
-        parts = [self.images.tensors, self.tgt.mask, self.tgt.flat_f, self.tgt.flat_i, self.t_cur.flats[0], self.t_cur.flats[1]]
+        # the image travels in the layout both networks consume (packed NHWC, 8 channels, the networks' dtype): the
+        # teacher's conversion of batch k is what the student reads one replay later instead of converting it again
+        snet, tnet = self.student.net, self.teacher.net
+        assert snet.dtype == tnet.dtype, "teacher and student share the converted input: same precision"
+        nhwc_cur = ops.image_to_nhwc(self.images.tensors, snet.dtype, 8)
+        parts = [nhwc_cur, self.tgt.mask, self.tgt.flat_f, self.tgt.flat_i, self.t_cur.flats[0], self.t_cur.flats[1]]
         offs, total = [], 0
         for t in parts:
             offs.append(total)
@@ -128,9 +147,10 @@ class GraphedKDStep:
             return [block[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(offs, parts)]
 
         cur, nxt = views(blocks[0]), views(blocks[1])
-        for side, images, tgt in ((cur, self.images, self.tgt), (nxt, self.images_nxt, self.tgt_nxt)):
-            side[0].copy_(images.tensors)
-            images.tensors = side[0]
+        cur[0].copy_(nhwc_cur)
+        ops.image_to_nhwc(self.images_nxt.tensors, snet.dtype, 8, out=nxt[0])
+        self._nhwc = (cur[0], nxt[0])
+        for side, tgt in ((cur, self.tgt), (nxt, self.tgt_nxt)):
             tgt.rebind_storage(side[1], side[2], side[3])
         cur[4].copy_(self.t_cur.flats[0]); cur[5].copy_(self.t_cur.flats[1])
         self.t_cur = TeacherKnowledge.from_flats(cur[4], cur[5], self.t_cur.batch, self.t_cur.cap)
@@ -158,7 +178,8 @@ class GraphedKDStep:
         snap = dict(params=st.params.clone(), bufs=st.bufs.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(),
                     nbt=self.student._nbt.clone(), steps=opt.steps, sc=getattr(opt, "_step_count", None))
         if self.pipeline:
-            snap.update(img=self.images.tensors.clone(), mask=self.tgt.mask.clone(), ff=self.tgt.flat_f.clone(),
+            snap.update(img=(self._nhwc[0] if self._nhwc is not None else self.images.tensors).clone(),
+                        mask=self.tgt.mask.clone(), ff=self.tgt.flat_f.clone(),
                         fi=self.tgt.flat_i.clone(), tf=self.t_cur.flats[0].clone(), ti=self.t_cur.flats[1].clone())
         return snap
 
@@ -173,7 +194,8 @@ class GraphedKDStep:
         if snap["sc"] is not None:
             opt._step_count = snap["sc"]
         if self.pipeline:                       # the warm-up iterations advanced the pipeline: rewind it
-            self.images.tensors.copy_(snap["img"]); self.tgt.mask.copy_(snap["mask"])
+            (self._nhwc[0] if self._nhwc is not None else self.images.tensors).copy_(snap["img"])
+            self.tgt.mask.copy_(snap["mask"])
             self.tgt.flat_f.copy_(snap["ff"]); self.tgt.flat_i.copy_(snap["fi"])
             self.t_cur.flats[0].copy_(snap["tf"]); self.t_cur.flats[1].copy_(snap["ti"])
 
@@ -247,6 +269,8 @@ class GraphedKDStep:
             else:                               # a new pipeline after flush(): the captured step's buffers stay
                 self.t_cur.copy_from(pred)
             self.images.tensors.copy_(self.images_nxt.tensors)
+            if self._nhwc is not None:
+                ops.image_to_nhwc(self.images_nxt.tensors, self.student.net.dtype, 8, out=self._nhwc[0])
             self.tgt.copy_from(self.tgt_nxt)
             self.primed = self.pending = True
             return None
