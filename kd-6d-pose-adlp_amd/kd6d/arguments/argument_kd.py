@@ -5,7 +5,6 @@ Every reference flag keeps its name, type and default.  Additive flags of this b
 overrides SOLVER.IMS_PER_BATCH), --image_size, --mixed_classes; yaml files may name a `_BASE_` file.
 """
 import argparse
-import copy
 import os
 
 import yaml

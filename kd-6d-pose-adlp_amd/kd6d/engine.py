@@ -11,7 +11,6 @@ models/model.py:40-103 (FPN), :370-451 (PoseHead).  Parameter NAMES and logical 
 reference state_dict; storage is KRSC with channels padded to multiples of 8.
 """
 import math
-import os
 
 import torch
 

@@ -21,7 +21,6 @@ still gets exactly one teacher forward and one student step; the losses returned
 to batch k-1 and `flush()` trains on the last pending batch.  The critical path of a call drops from
 teacher + student to max(teacher, student), and the two halves fill each other's idle CUs.
 """
-import os
 
 import torch
 

@@ -10,7 +10,6 @@ store) and the fall-back route for CPU tensors (the gloo tests) or when librccl 
 """
 import ctypes
 import math
-import os
 
 import torch
 from torch import distributed as dist

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from .. import kd_losses, ops
+from .. import ops
 from ..kd_losses import KDLoss, PackedTargets, TeacherKnowledge
 
 _DENSE_DIMS = (2, 4, 8, 16)

@@ -150,10 +150,9 @@ class PoseModuleKD(nn.Module):
     def zero_grad(self, set_to_none=False):
         st = self.net.store
         st.ensure_grads()
-        if self._parameters or True:
-            first = _get_shell(self, ["head", "cls_logits"])._parameters["weight"]
-            if first.grad is None:
-                self._bind_grads()
+        first = _get_shell(self, ["head", "cls_logits"])._parameters["weight"]
+        if first.grad is None:
+            self._bind_grads()
         st.grads.zero_()
 
     def state_dict(self, *args, **kwargs):

@@ -31,7 +31,6 @@ from kd6d._lib import lib  # noqa: E402
 from kd6d.kd_losses import PackedTargets  # noqa: E402
 from kd6d.libs.distributed import get_rank, init_exchange, shard_batch, synchronize  # noqa: E402
 from kd6d.libs.eval_libs import valid  # noqa: E402
-from kd6d.libs.poses import ImageList  # noqa: E402
 from kd6d.libs.train_libs import build_dataset, build_model, build_model_teacher, dataset_meshes  # noqa: E402
 from kd6d.models.model_kd import PoseModuleKD as PoseModule  # noqa: E402
 from kd6d.synthetic import make_batch  # noqa: E402
