@@ -20,7 +20,7 @@
 // zeros (fetched from a zero page), so tap kx of position q is position q + kx - 1 with no per-pixel validity
 // mask anywhere in the k-loop; rows above / below the image are zero-page fetches decided by the loader, which
 // computes a source address per lane anyway.  Tiles land in LDS in their natural layout (row = position) by
-// LDS-DMA (global_load_lds_dwordx4, 3-stage ring, counted vmcnt, one raw s_barrier per step) with the chunk
+// LDS-DMA (2-stage ring, counted vmcnt, one raw s_barrier per step) with the chunk
 // swizzle applied on the source side; MFMA fragments (8 consecutive positions of one channel per lane) come
 // out of ds_read_b64_tr_b16.  A = X^T fragment, B = dY fragment, so a lane ends with 4 consecutive j of one n:
 // 16-B stores of the fp32 partial tile into a slab; a second small kernel sums the slabs of a tile's splits and
@@ -128,7 +128,7 @@ __device__ __forceinline__ void wgrad_body(const GProblem& p, const GTile& t, co
   constexpr int DBYTES = KSTEP * DP;
   constexpr int STAGE = DBYTES + XI * 1024;
   static_assert(WN * WJ == 8 && NI >= 1 && JI >= 1 && KSTEP % DRPI == 0, "tile shape");
-  static_assert(NS >= 3 && NS <= 4 && NS * STAGE <= 160 * 1024, "LDS ring");
+  static_assert(NS >= 2 && NS <= 4 && NS * STAGE <= 160 * 1024, "LDS ring");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform on purpose: scalar branches / addresses
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_group_kernel(const char* __res
   const GProblem& p = reinterpret_cast<const GProblem*>(plan + h->off_problems)[t.problem];
   float* my = slab + (size_t)blockIdx.x * kSlabStride;
   switch (t.variant) {
-    case V_128x3: wgrad_body<128, 2, 4, 128, 3, 4>(p, t, w, my, smem); break;
-    case V_16x3: wgrad_body<16, 1, 8, 128, 3, 4>(p, t, w, my, smem); break;
-    case V_128x1: wgrad_body<128, 2, 4, 128, 1, 4>(p, t, w, my, smem); break;
-    default: wgrad_body<16, 1, 8, 128, 1, 4>(p, t, w, my, smem); break;
+    case V_128x3: wgrad_body<128, 2, 4, 128, 3, 2>(p, t, w, my, smem); break;
+    case V_16x3: wgrad_body<16, 1, 8, 128, 3, 2>(p, t, w, my, smem); break;
+    case V_128x1: wgrad_body<128, 2, 4, 128, 1, 2>(p, t, w, my, smem); break;
+    default: wgrad_body<16, 1, 8, 128, 1, 2>(p, t, w, my, smem); break;
   }
 }
 
@@ -417,7 +417,9 @@ bool item_supported(const kd6d_conv_geom* g, int dtype) {
   return true;
 }
 
-constexpr int kLdsBytes = 4 * (KSTEP * 256 + 17 * 1024);
+// two stages = 67 KB (2, 3 and 4 stages measured the same launch time: the loop waits on the per-CU miss window, not
+// on ring depth), so two of these workgroups -- or one and a two-per-CU halo tile -- share a CU
+constexpr int kLdsBytes = 2 * (KSTEP * 256 + 17 * 1024);
 
 }  // namespace
 
