@@ -182,6 +182,12 @@ typedef struct kd6d_zero_list {
 } kd6d_zero_list;
 int kd6d_zero_regions(const kd6d_zero_list* list, long long* counter, int n_counter, void* stream);
 
+/* n uniform [0, 1) fp32 keys for kd6d_ssc_assign (the random in-mask cells of losses/loss.py:224-228), generated on
+ * the device from (seed, *counter, index): *counter is a device int64 the caller advances every step (the step
+ * prologue's counters), so a captured launch draws new keys at every replay.  Not torch's generator: the sequence is
+ * reproducible from the seed and the step count alone. */
+int kd6d_uniform_keys(float* out, int64_t n, const long long* counter, unsigned long long seed, void* stream);
+
 /* Timing aid: stores the device's 100-MHz wall clock into *slot when the launch executes on `stream`
  * (phase boundaries inside a replayed hipGraph; tools/step_timeline.py). */
 int kd6d_mark(unsigned long long* slot, void* stream);

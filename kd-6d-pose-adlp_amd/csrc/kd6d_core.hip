@@ -136,3 +136,35 @@ extern "C" int kd6d_zero_regions(const kd6d_zero_list* list, long long* counter,
   KD6D_CHECK_LAUNCH("kd6d_zero_regions");
   return KD6D_OK;
 }
+
+// Uniform [0, 1) keys for the SSC sampling of losses/loss.py:224-228 (the reference draws torch.randperm per ground
+// truth and level; a uniform key per cell and "the n_k smallest keys inside the mask" is the same distribution).
+// Counter-based: key(i) = mix(seed, *counter, i) with the splitmix64 finaliser, so a replayed hipGraph draws fresh keys
+// every step from the step counter the prologue increments -- torch's generator inside a captured graph costs a key
+// kernel plus two seed / offset fills per replay.
+namespace {
+__global__ __launch_bounds__(256) void uniform_keys_kernel(float* __restrict__ out, long long n,
+                                                           const long long* __restrict__ counter,
+                                                           unsigned long long seed) {
+  const unsigned long long step = (unsigned long long)counter[0];
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    unsigned long long z = seed + step * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = (float)(z >> 40) * (1.0f / 16777216.0f);      // 24 random bits: every value is exact in fp32, < 1
+  }
+}
+}  // namespace
+
+extern "C" int kd6d_uniform_keys(float* out, int64_t n, const long long* counter, unsigned long long seed,
+                                 void* stream) {
+  KD6D_CHECK_ARG(out && counter && n > 0, "kd6d_uniform_keys: bad arguments");
+  long long blocks = (n + 256 * 4 - 1) / (256 * 4);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(uniform_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     out, (long long)n, counter, seed);
+  KD6D_CHECK_LAUNCH("kd6d_uniform_keys");
+  return KD6D_OK;
+}

@@ -69,6 +69,7 @@ SIGNATURES = {
     "kd6d_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)],
     "kd6d_reset_options": [],
     "kd6d_zero_regions": [ctypes.POINTER(ZeroList), _P, _I, _P],
+    "kd6d_uniform_keys": [_P, _I64, _P, ctypes.c_uint64, _P],
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],

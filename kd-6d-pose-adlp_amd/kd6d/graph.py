@@ -137,7 +137,8 @@ class GraphedKDStep:
         snet, tnet = self.student.net, self.teacher.net
         assert snet.dtype == tnet.dtype, "teacher and student share the converted input: same precision"
         nhwc_cur = ops.image_to_nhwc(self.images.tensors, snet.dtype, 8)
-        parts = [nhwc_cur, self.tgt.mask, self.tgt.flat_f, self.tgt.flat_i, self.t_cur.flats[0], self.t_cur.flats[1]]
+        tgt_bytes = torch.empty(self.tgt.block_bytes(), dtype=torch.uint8, device=dev)      # shape donor only
+        parts = [nhwc_cur, tgt_bytes, self.t_cur.flats[0], self.t_cur.flats[1]]
         offs, total = [], 0
         for t in parts:
             offs.append(total)
@@ -152,10 +153,10 @@ class GraphedKDStep:
         ops.image_to_nhwc(self.images_nxt.tensors, snet.dtype, 8, out=nxt[0])
         self._nhwc = (cur[0], nxt[0])
         for side, tgt in ((cur, self.tgt), (nxt, self.tgt_nxt)):
-            tgt.rebind_storage(side[1], side[2], side[3])
-        cur[4].copy_(self.t_cur.flats[0]); cur[5].copy_(self.t_cur.flats[1])
-        self.t_cur = TeacherKnowledge.from_flats(cur[4], cur[5], self.t_cur.batch, self.t_cur.cap)
-        self.teacher._teacher_flats = (nxt[4], nxt[5])     # the teacher's selection writes straight into the next block
+            tgt.rebind_block(side[1])
+        cur[2].copy_(self.t_cur.flats[0]); cur[3].copy_(self.t_cur.flats[1])
+        self.t_cur = TeacherKnowledge.from_flats(cur[2], cur[3], self.t_cur.batch, self.t_cur.cap)
+        self.teacher._teacher_flats = (nxt[2], nxt[3])     # the teacher's selection writes straight into the next block
         self._blocks = blocks
 
     # ---- static inputs ------------------------------------------------------------------------

@@ -69,8 +69,7 @@ class PackedTargets:
     _SMALL_I = ("class_ids", "n_gt")
 
     def _pack_small(self):
-        """Re-home the small per-image fields as views of one fp32 and one int32 buffer, so that a static
-        (hipGraph) copy of a batch is 3 device copies (mask, floats, ints) instead of 8."""
+        """Re-home the small per-image fields as views of one fp32 and one int32 buffer (8 tensors -> 2)."""
         for names, attr in ((self._SMALL_F, "flat_f"), (self._SMALL_I, "flat_i")):
             parts = [getattr(self, n) for n in names]
             sizes = [(p.numel() + 3) // 4 * 4 for p in parts]          # keep every view 16-byte aligned
@@ -82,6 +81,37 @@ class PackedTargets:
                 setattr(self, n, v)
                 off += sz
             setattr(self, attr, flat)
+        # ... and mask, floats, ints in ONE block, so that a static copy of a batch is one device copy
+        self.block = None
+        self._into_block(torch.zeros(self.block_bytes(), dtype=torch.uint8, device=self.mask.device))
+
+    def _block_layout(self):
+        """Byte offsets of (mask, flat_f, flat_i) inside one block, each segment 256-byte aligned, and the total."""
+        sizes = [t.numel() * t.element_size() for t in (self.mask, self.flat_f, self.flat_i)]
+        offs, total = [], 0
+        for sz in sizes:
+            offs.append(total)
+            total += (sz + 255) // 256 * 256
+        return offs, sizes, total
+
+    def _into_block(self, block):
+        """Re-home mask / flat_f / flat_i as views of `block` (uint8, _block_layout()'s size); contents are copied."""
+        offs, sizes, total = self._block_layout()
+        assert block.dtype == torch.uint8 and block.numel() == total
+        new = [block[o:o + sz].view(t.dtype).view(t.shape)
+               for o, sz, t in zip(offs, sizes, (self.mask, self.flat_f, self.flat_i))]
+        for n, t in zip(new, (self.mask, self.flat_f, self.flat_i)):
+            n.copy_(t)
+        self.mask, self.flat_f, self.flat_i = new
+        self.block = block
+        self._rebind()
+
+    def block_bytes(self):
+        return self._block_layout()[2]
+
+    def rebind_block(self, block):
+        """Move the batch into caller-owned storage (GraphedKDStep's hand-over blocks); contents are copied."""
+        self._into_block(block)
 
     def clone_static(self):
         out = object.__new__(PackedTargets)
@@ -90,6 +120,8 @@ class PackedTargets:
         for names, attr in ((self._SMALL_F, "flat_f"), (self._SMALL_I, "flat_i")):
             setattr(out, attr, getattr(self, attr).clone())
         out._rebind()
+        out.block = None
+        out._into_block(torch.zeros(out.block_bytes(), dtype=torch.uint8, device=out.mask.device))
         return out
 
     def _rebind(self):
@@ -101,6 +133,12 @@ class PackedTargets:
                 off += (old.numel() + 3) // 4 * 4
 
     def copy_from(self, other):
+        """One device copy when both sides keep their batch in one block of the same layout (every PackedTargets
+        built by __init__ / clone_static does), three otherwise."""
+        mine, theirs = getattr(self, "block", None), getattr(other, "block", None)
+        if mine is not None and theirs is not None and mine.numel() == theirs.numel():
+            mine.copy_(theirs, non_blocking=True)
+            return
         self.mask.copy_(other.mask, non_blocking=True)
         self.flat_f.copy_(other.flat_f, non_blocking=True)
         self.flat_i.copy_(other.flat_i, non_blocking=True)
@@ -111,6 +149,7 @@ class PackedTargets:
             assert new.shape == old.shape and new.dtype == old.dtype
             new.copy_(old)
         self.mask, self.flat_f, self.flat_i = mask, flat_f, flat_i
+        self.block = None
         self._rebind()
 
 
@@ -241,6 +280,8 @@ class KDLoss:
         self.cap = cap
         self.ctx = None
         self._ws = {}
+        self._keys = {}
+        self.seed = torch.initial_seed()      # device-side sampling keys: reproducible from torch.manual_seed
         self.anchor_sizes, self.anchor_strides = ANCHOR_SIZES, ANCHOR_STRIDES      # configs/ape.yaml:3-4
 
     def workspaces(self, batch, device):
@@ -254,15 +295,22 @@ class KDLoss:
                                   torch.zeros(3 * bp + 4 + 2 * n, dtype=torch.int32, device=device))
         return ws
 
-    def assign(self, levels, batch, tgt, keys=None, prezeroed=False):
+    def assign(self, levels, batch, tgt, keys=None, prezeroed=False, step_counter=None):
         """SSC target assignment + the zeroed per-step workspaces.  Depends on the targets only, not on the student's
         output: the graphed step runs it on a side stream beside the student's forward.  prezeroed: the workspaces
-        are the persistent pair of workspaces(), already zeroed by the step prologue."""
+        are the persistent pair of workspaces(), already zeroed by the step prologue.  keys: the sampling keys (tests
+        pin them); otherwise drawn here -- on the device from (seed, step_counter[0], cell) when the caller has a
+        device step counter (graph-replayable without torch's generator), else by torch.rand."""
         dev = tgt.mask.device
         rows = batch * sum(h * w for h, w in levels)
         cap = self.cap
         lv = make_levels(batch, levels, self.anchor_sizes, self.anchor_strides)
-        if keys is None:
+        if keys is None and step_counter is not None:
+            kb = self._keys.get((rows, str(dev)))
+            if kb is None:
+                kb = self._keys[(rows, str(dev))] = torch.empty(rows, dtype=torch.float32, device=dev)
+            keys = ops.uniform_keys(kb, step_counter, self.seed)
+        elif keys is None:
             keys = torch.rand(rows, dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)

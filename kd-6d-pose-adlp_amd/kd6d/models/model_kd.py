@@ -269,7 +269,8 @@ class PoseModuleKD(nn.Module):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pre = self.loss_evaluator.assign(net.levels, B, tgt, keys, prezeroed=prezeroed)
+                pre = self.loss_evaluator.assign(net.levels, B, tgt, keys, prezeroed=prezeroed,
+                                                 step_counter=self._nbt if prezeroed else None)
         cls, reg = net.forward(x, scratch_zeroed=prezeroed)
         if pre is not None:
             torch.cuda.current_stream().wait_stream(side)

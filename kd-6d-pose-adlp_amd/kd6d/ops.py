@@ -196,6 +196,14 @@ def zero_many(tensors, counter=None):
                                 counter.numel() if counter is not None else 0, _stream()), "kd6d_zero_regions")
 
 
+def uniform_keys(out, counter, seed):
+    """kd6d_uniform_keys: out (fp32, device) <- uniform [0, 1) keys of (seed, counter[0], index)."""
+    assert out.dtype == torch.float32 and counter.dtype == torch.int64
+    check(lib.kd6d_uniform_keys(_ptr(out), out.numel(), _ptr(counter), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+          "kd6d_uniform_keys")
+    return out
+
+
 def device_cu_count():
     n = lib.kd6d_device_cu_count()
     if n <= 0:

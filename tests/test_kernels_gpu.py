@@ -976,3 +976,27 @@ def test_zero_regions_step_prologue(gpu_device):
     assert counter.tolist() == list(range(2, 13))
     with pytest.raises(RuntimeError, match="16-B aligned"):
         ops.zero_many([guards[0][1:9]])
+
+
+def test_uniform_keys_counter_based(gpu_device):
+    """kd6d_uniform_keys: values in [0, 1), uniform (mean, variance, decile counts), reproducible from (seed, counter),
+    different for another counter or seed, no repeats between neighbouring cells."""
+    ops = _ops()
+    dev = gpu_device
+    n = 1 << 18
+    c3 = torch.tensor([3, 99], dtype=torch.int64, device=dev)
+    c4 = torch.tensor([4], dtype=torch.int64, device=dev)
+    a = ops.uniform_keys(torch.empty(n, device=dev), c3, 1234).clone()
+    b = ops.uniform_keys(torch.empty(n, device=dev), c3, 1234)
+    c = ops.uniform_keys(torch.empty(n, device=dev), c4, 1234)
+    d = ops.uniform_keys(torch.empty(n, device=dev), c3, 1235)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert float(a.min()) >= 0.0 and float(a.max()) < 1.0
+    assert abs(float(a.mean()) - 0.5) < 5e-3 and abs(float(a.var()) - 1.0 / 12.0) < 2e-3
+    hist = torch.histc(a, bins=10, min=0.0, max=1.0)
+    assert float((hist - n / 10).abs().max()) < 6 * (n / 10) ** 0.5
+    for other in (c, d):
+        assert float((a == other).float().mean()) < 1e-3
+        assert abs(float(((a - 0.5) * (other - 0.5)).mean())) < 1e-3          # uncorrelated streams
+    assert float((a[1:] == a[:-1]).float().mean()) < 1e-3
