@@ -307,7 +307,8 @@ def main():
                                               args.student, args.precision, B,
                                               "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "exchange": route,
-                          "launch": "eager" if gstep is None else ("hipGraph replay (2 graphs/step)" + (
+                          "launch": "eager" if gstep is None else ("hipGraph replay (%d graph%s/step)" % (
+                              gstep.graphs_per_step, "" if gstep.graphs_per_step == 1 else "s") + (
                               "" if not gstep.pipeline else ", teacher(k+1) overlapped with student step(k)")),
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
                "losses_last_step": losses, "finite": finite, "barrier_timeouts": barrier_timeouts,

@@ -63,6 +63,7 @@ class GraphedKDStep:
         self.warmup = warmup
         self.pipeline = pipeline
         self.g_step = self.g_opt = None
+        self.graphs_per_step = 2
         self.images = self.tgt = self.losses = None        # the batch the student trains on
         self.images_nxt = self.tgt_nxt = None              # pipeline: the batch the teacher looks at
         self.t_cur = None                                  # pipeline: teacher cells of `images`
@@ -220,13 +221,20 @@ class GraphedKDStep:
                 self._count_opt_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # Without a gradient exchange (one rank) nothing has to happen between the reverse sweep and the optimiser:
+        # ONE graph per step, and the eager kd6d_set_hyper launch moves in front of it.  With an exchange the RCCL
+        # all-reduce sits between two graphs.
+        self.graphs_per_step = 2 if D.exchange_active() else 1
         self.g_step = torch.cuda.CUDAGraph()
         # thread-local capture mode: with a process group alive, RCCL's watchdog thread polls events concurrently
         with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
             self.losses = self._forward_backward()
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, pool=self.g_step.pool(), capture_error_mode="thread_local"):
-            self.opt.launch(device_schedule=True)
+            if self.graphs_per_step == 1:
+                self.opt.launch(device_schedule=True)
+        if self.graphs_per_step == 2:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_step.pool(), capture_error_mode="thread_local"):
+                self.opt.launch(device_schedule=True)
         self._restore(snap)
 
     def _exchange(self):
@@ -240,10 +248,14 @@ class GraphedKDStep:
             self.opt._step_count += 1
 
     def _replay(self):
-        self.g_step.replay()
-        self._exchange()
-        self.opt.advance()
-        self.g_opt.replay()
+        if self.graphs_per_step == 1:
+            self.opt.advance()                 # lr / bias corrections of THIS step, consumed at the graph's end
+            self.g_step.replay()
+        else:
+            self.g_step.replay()
+            self._exchange()
+            self.opt.advance()
+            self.g_opt.replay()
         self._count_opt_step()
         for _, bn in self.student.net.bns:     # what FusedClipAdamW.launch() does when it runs from Python: the
             bn.fold = None                     # cached eval-mode BN scale/shift belong to the previous weights

@@ -1,5 +1,5 @@
 """Parity at the sizes BASELINE.json is quoted on (config 2: B = 16, 256x256 DZI crops, darknet53 -> darknet_tiny_h),
-through the launch mode bench.py times (GraphedKDStep(pipeline=True): 2 hipGraphs per step, the teacher of batch k+1
+through the launch mode bench.py times (GraphedKDStep(pipeline=True): the replayed hipGraph step, the teacher of batch k+1
 beside the student step of batch k), against oracle/kd_step_ref.py on the same seeded inputs.
 
 At this size the per-layer dispatcher picks kernels the B = 2 / 128x128 cases of test_step_gpu.py never reach inside a
