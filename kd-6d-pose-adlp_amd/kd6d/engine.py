@@ -361,6 +361,7 @@ class PoseNet:
         self.grouping = False          # True while the reverse sweep is inside the section whose dW are collected
         self.use_wgrad_group = True
         self.wgrad_group_wgs = 0
+        self.wgrad_group_flush = "head_end"     # or "fpn_end" (GraphedKDStep picks by launch mode)
         self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
         self.pair_towers = 1
@@ -778,9 +779,12 @@ class PoseNet:
                     self.wgrad_group.add(g, inner, dslot(pos), self.store.storage(conv.w, "grads"),
                                          self.store.storage(conv.b, "grads"), flops=conv.flops(g))
                     grouped_out.add(i)
-            # launched here, beside the FPN / backbone sweep: at the very end of the sweep the same launch cost 2-7 %
-            # of the step (it then runs with nothing beside it)
-            self.flush_wgrad_group()
+            # launched here, beside the FPN / backbone sweep, when a teacher forward shares the device (pipelined
+            # steps: 5363-5382 images/s against 5107-5135 with the launch behind the FPN sweep); strictly sequential
+            # steps launch it behind the FPN sweep, beside the backbone sweep's chain of small launches (4836 against
+            # 4655).  At the very end of the sweep it costs 2-7 % of the step (it then runs with nothing beside it).
+            if self.wgrad_group_flush != "fpn_end":
+                self.flush_wgrad_group()
         self.grouping = False
         # P7 = conv(relu(P6)); P6 = conv(top feature)
         ftop, lvtop, p6, p6r, h6 = self.p6_ctx
@@ -807,6 +811,8 @@ class PoseNet:
                 dfeat[i] = self.inner[i].bwd(f, d_inner, B, lv, dx=self.buf("dfeat%d" % i, f.shape))
             d_inner_up = (d_inner, h, w)
         ops.mark("student.bwd.fpn.end")
+        if self.wgrad_group is not None and self.wgrad_group_flush == "fpn_end":
+            self.flush_wgrad_group()
         # ---- backbone (tiny): walk the tape in reverse ----
         # feats index -> gradient arriving from the FPN; out4 = index 3 (after stage 5), out3 = index 2
         grad = dfeat[top]

@@ -57,6 +57,7 @@ class GraphedKDStep:
         # grouped head weight gradients: one workgroup per two CUs beside a teacher forward (5284-5292 images/s against
         # 5215-5234 at one per CU and 5208-5214 at two), two per CU when the step is strictly sequential (4553 against 4467)
         snet.wgrad_group_wgs = ops.device_cu_count() // 2 if pipeline else 2 * ops.device_cu_count()
+        snet.wgrad_group_flush = "head_end" if pipeline else "fpn_end"      # measured, see PoseNet.backward
         self.w_cls, self.w_reg, self.w_kd = (float(w) for w in loss_weights)
         self._w = None                                     # the same weights as a device tensor
         self.cfg_kd = cfg_kd
