@@ -262,6 +262,24 @@ int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t
 int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, const int32_t* level_hw_host,
                      int nseg, int batch, int C, int groups, const float* gamma, const float* beta, float eps,
                      const float* stats, float* gsum_ws, float* dgamma, float* dbeta, int flags, void* stream);
+/* Two GroupNorm+ReLU backwards of identical geometry (the cls and the pose tower layer of PoseHead,
+ * models/model.py:438-451) as ONE launch of the in-kernel-barrier form: alone each is 170 four-wave workgroups on
+ * 256 CUs.  Same arguments as kd6d_gn_relu_bwd, the per-tensor ones in an item each; falls back to two launches
+ * where the one-launch form does not apply (gn.onepass = 0, too few resident workgroups). */
+typedef struct kd6d_gn_item {
+  const void* x;
+  const void* dz;
+  void* dx;
+  const float* gamma;
+  const float* beta;
+  const float* stats;
+  float* gsum_ws;
+  float* dgamma;
+  float* dbeta;
+} kd6d_gn_item;
+int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a, const kd6d_gn_item* b,
+                          const int32_t* level_hw_host, int nseg, int batch, int C, int groups, float eps, int flags,
+                          void* stream);
 
 /* MaxPool2d(2,2) (backbone/darknet.py:94-97), nearest-x2 upsample + add (models/model.py:75-78)
  * and its adjoint, ReLU / ReLU-backward / add (mode 0/1/2), NCHW fp32 image -> padded NHWC. */

@@ -988,15 +988,15 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
 // group is far smaller than the number of resident workgroups, so the wait always ends.
 constexpr int kGnHold = 8;
 template <typename T, typename TX>
-__global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
-    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm, float eps,
+__device__ __forceinline__ void gn_relu_bwd_onepass_body(
+    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, const GnGeom& gm, float eps,
     const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* gsum, unsigned int* counters, float* dgamma, float* dbeta) {
+    float* gsum, unsigned int* counters, float* dgamma, float* dbeta, int bid) {
   constexpr int EG = Granule<T>::N;
   __shared__ float s_a[64], s_b[64];
   extern __shared__ float red[];  // 2*C
   int seg, b, r_begin, r_cnt;
-  gn_chunk(gm, blockIdx.x, seg, b, r_begin, r_cnt);
+  gn_chunk(gm, bid, seg, b, r_begin, r_cnt);
   int hw = 1;
 #pragma unroll
   for (int s = 0; s < KD6D_MAX_SEG; ++s)
@@ -1095,6 +1095,30 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
     if (dbeta) atomicAdd(dbeta + c, red[c]);
     if (dgamma) atomicAdd(dgamma + c, red[C + c]);
   }
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
+    const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm, float eps,
+    const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* gsum, unsigned int* counters, float* dgamma, float* dbeta) {
+  gn_relu_bwd_onepass_body<T, TX>(x, dz, dx, gm, eps, stats, gamma, beta, gsum, counters, dgamma, dbeta, blockIdx.x);
+}
+
+// Two GroupNorm backwards of identical geometry (the cls and the pose tower layer of the head) as ONE launch:
+// workgroups [0, gm.nblk) take the first tensor set, the rest the second.  One of them alone is 170 workgroups of
+// 4 waves on 256 CUs and latency-bound; back to back on one stream the second waited for the first.
+struct GnBwdSet {
+  const void* x; const void* dz; void* dx;
+  const float* stats; const float* gamma; const float* beta;
+  float* gsum; unsigned int* counters; float* dgamma; float* dbeta;
+};
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_pair_kernel(GnBwdSet a, GnBwdSet b, GnGeom gm, float eps) {
+  const bool first = (int)blockIdx.x < gm.nblk;
+  const GnBwdSet& q = first ? a : b;
+  gn_relu_bwd_onepass_body<T, TX>((const TX*)q.x, (const T*)q.dz, (T*)q.dx, gm, eps, q.stats, q.gamma, q.beta, q.gsum,
+                                  q.counters, q.dgamma, q.dbeta, first ? blockIdx.x : blockIdx.x - gm.nblk);
 }
 
 template <typename T, typename TX>
@@ -1728,6 +1752,60 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
                        (const T_*)dz, (T_*)dx, gm, ngran, eps, stats, gsum_ws, gamma, beta);
   });
   KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a, const kd6d_gn_item* b,
+                                     const int32_t* level_hw_host, int nseg, int batch, int C, int groups, float eps,
+                                     int flags, void* stream) {
+  KD6D_CHECK_ARG(a && b, "kd6d_gn_relu_bwd_pair: null item");
+  // the one-launch form exists for the in-kernel-barrier backward only; everything else goes out one by one
+  int chunk = 0;
+  GnGeom g1;
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  bool pair = gn_onepass() && check_channels(dtype, C, "kd6d_gn_relu_bwd_pair") == KD6D_OK && level_hw_host;
+  if (pair) {
+    const int cgs = C / eg;
+    chunk = gn_chunk_rows();
+    if (chunk * cgs > kGnHold * kThreads) chunk = kGnHold * kThreads / cgs;
+    pair = chunk >= 1 && (C / groups) * 2 >= eg && fill_gn(level_hw_host, nseg, batch, C, groups, &g1, chunk);
+  }
+  if (pair) {
+    int gcap = 0, gmax = 1;
+    DISPATCH_TTX(dtype, x_f32, gcap = (gn_onepass_capacity<T_, TX_>()));
+    for (int s = 0; s < nseg; ++s) gmax = g1.cps[s] > gmax ? g1.cps[s] : gmax;
+    pair = gcap >= 4 * gmax;                 // two launches' worth of siblings resident at once
+  }
+  const kd6d_gn_item* it[2] = {a, b};
+  if (!pair) {
+    for (int i = 0; i < 2; ++i) {
+      const int rc = kd6d_gn_relu_bwd(dtype, x_f32, it[i]->x, it[i]->dz, it[i]->dx, level_hw_host, nseg, batch, C, groups,
+                                      it[i]->gamma, it[i]->beta, eps, it[i]->stats, it[i]->gsum_ws, it[i]->dgamma,
+                                      it[i]->dbeta, flags, stream);
+      if (rc) return rc;
+    }
+    return KD6D_OK;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GnBwdSet sets[2];
+  for (int i = 0; i < 2; ++i) {
+    KD6D_CHECK_ARG(it[i]->x && it[i]->dz && it[i]->dx && it[i]->gamma && it[i]->beta && it[i]->stats && it[i]->gsum_ws,
+                   "kd6d_gn_relu_bwd_pair: null pointer in item %d", i);
+    unsigned int* counters = reinterpret_cast<unsigned int*>(it[i]->gsum_ws + 2 * (size_t)nseg * batch * groups);
+    if (!(flags & KD6D_GN_WS_ZEROED) &&
+        hipMemsetAsync(it[i]->gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups + sizeof(unsigned int) * (size_t)nseg * batch,
+                       st) != hipSuccess) {
+      kd6d_set_error("kd6d_gn_relu_bwd_pair: memset failed");
+      return KD6D_ERR_LAUNCH;
+    }
+    sets[i] = GnBwdSet{it[i]->x, it[i]->dz, it[i]->dx, it[i]->stats, it[i]->gamma, it[i]->beta, it[i]->gsum_ws, counters,
+                       it[i]->dgamma, it[i]->dbeta};
+  }
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  DISPATCH_TTX(dtype, x_f32,
+               hipLaunchKernelGGL((gn_relu_bwd_onepass_pair_kernel<T_, TX_>), dim3(2 * g1.nblk), dim3(kThreads), lds, st,
+                                  sets[0], sets[1], g1, eps));
+  KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd_pair");
   return KD6D_OK;
 }
 

@@ -47,6 +47,10 @@ MAX_GT = 4
 MAX_ZERO = 8
 
 
+class GnItem(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dz", "dx", "gamma", "beta", "stats", "gsum_ws", "dgamma", "dbeta")]
+
+
 class ZeroList(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("pad_", ctypes.c_int32), ("ptr", ctypes.c_void_p * MAX_ZERO),
                 ("bytes", ctypes.c_int64 * MAX_ZERO)]
@@ -91,6 +95,8 @@ SIGNATURES = {
     "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P,
                          _P, _P, _P, _I, _P],
+    "kd6d_gn_relu_bwd_pair": [_I, _I, ctypes.POINTER(GnItem), ctypes.POINTER(GnItem), ctypes.POINTER(ctypes.c_int32),
+                              _I, _I, _I, _I, _F, _I, _P],
     "kd6d_maxpool2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
     "kd6d_maxpool2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kd6d_upsample2_add": [_I, _P, _P, _P, _I, _I, _I, _I, _P],

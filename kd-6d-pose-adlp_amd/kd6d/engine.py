@@ -322,13 +322,17 @@ class GroupNormReLU:
                         self.stats(batch, levels), flags=ops.GN_STATS_READY)
         return out
 
-    def bwd(self, x, dz, batch, levels, dx):
+    def bwd_item(self, x, dz, batch, levels, dx):
+        """The argument tuple of ops.gn_relu_bwd / gn_relu_bwd_pair for this layer."""
         net, st = self.net, self.net.store
-        hw = [h * w for (h, w) in levels]
-        stats = self.stats(batch, levels)
         gsum = net.scratch(self.name + ".gsum", ops.gn_bwd_workspace_floats(len(levels), batch, self.groups))
-        ops.gn_relu_bwd(x, dz, dx, hw, batch, self.groups, st.storage(self.gamma), st.storage(self.beta), stats,
-                        gsum, st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"),
+        return (x, dz, dx, st.storage(self.gamma), st.storage(self.beta), self.stats(batch, levels), gsum,
+                st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"))
+
+    def bwd(self, x, dz, batch, levels, dx):
+        hw = [h * w for (h, w) in levels]
+        x, dz, dx, gamma, beta, stats, gsum, dgamma, dbeta = self.bwd_item(x, dz, batch, levels, dx)
+        ops.gn_relu_bwd(x, dz, dx, hw, batch, self.groups, gamma, beta, stats, gsum, dgamma, dbeta,
                         flags=ops.GN_WS_ZEROED)
         return dx
 
@@ -728,11 +732,15 @@ class PoseNet:
                 saved, last = self.head_ctx[tname]
                 dxs[tname] = final.bwd(last, dlog, B, lv_all, dx=self.buf("%s.dact" % tname, (r, oc)))
             for li in range(len(self.cls_tower) - 1, -1, -1):
-                draws = {}
+                # the two GroupNorm backwards of the layer as one launch (170 four-wave workgroups each: alone they
+                # are latency-bound and, back to back on one stream, the second waited for the first)
+                draws, items = {}, []
                 for tname, tower, _, _ in towers:
                     gn = tower[li][1]
-                    draws[tname] = gn.bwd(self.head_ctx[tname][0][li][1], dxs[tname], B, lv_all,
-                                          self.buf("%s.draw%d" % (tname, li), (r, oc)))
+                    draws[tname] = self.buf("%s.draw%d" % (tname, li), (r, oc))
+                    items.append(gn.bwd_item(self.head_ctx[tname][0][li][1], dxs[tname], B, lv_all, draws[tname]))
+                ops.gn_relu_bwd_pair(items, [h * w for (h, w) in lv_all], B, self.cls_tower[li][1].groups,
+                                     flags=ops.GN_WS_ZEROED)
                 if li > 0:
                     # the two data gradients as one launch; the weight gradients fork onto the side streams as usual
                     with ops.conv_pair(enabled=self.pair_towers == 1):

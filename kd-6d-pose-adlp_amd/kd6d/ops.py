@@ -366,6 +366,27 @@ def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws,
     return dx
 
 
+def gn_relu_bwd_pair(items, level_hw, batch, groups, eps=1e-5, flags=0):
+    """Two gn_relu_bwd of identical geometry as one launch (kd6d_gn_relu_bwd_pair).  items: two tuples
+    (x, dz, dx, gamma, beta, stats, gsum_ws, dgamma, dbeta)."""
+    assert len(items) == 2
+    packed = []
+    for (x, dz, dx, gamma, beta, stats, gsum_ws, dgamma, dbeta) in items:
+        rows, c = x.shape
+        assert rows == batch * sum(level_hw) and x.shape == items[0][0].shape and dz.dtype == items[0][1].dtype
+        assert gsum_ws.numel() >= gn_bwd_workspace_floats(len(level_hw), batch, groups), "gsum_ws too small (kd6d.h)"
+        it = _lib.GnItem()
+        for name, t in zip(("x", "dz", "dx", "gamma", "beta", "stats", "gsum_ws", "dgamma", "dbeta"),
+                           (x, dz, dx, gamma, beta, stats, gsum_ws, dgamma, dbeta)):
+            assert t is None or (t.is_cuda and t.is_contiguous())
+            setattr(it, name, t.data_ptr() if t is not None else None)
+        packed.append(it)
+    x0, dz0 = items[0][0], items[0][1]
+    check(lib.kd6d_gn_relu_bwd_pair(dt_code(dz0.dtype), _xf32(x0, dz0.dtype), ctypes.byref(packed[0]),
+                                    ctypes.byref(packed[1]), _hw_array(level_hw), len(level_hw), batch, x0.shape[1],
+                                    groups, eps, flags, _stream()), "kd6d_gn_relu_bwd_pair")
+
+
 def maxpool2_fwd(x, y, b, h, w):
     c = x.shape[-1]
     check(lib.kd6d_maxpool2_fwd(dt_code(x.dtype), _ptr(x), _ptr(y), b, h, w, c, _stream()),

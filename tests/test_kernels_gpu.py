@@ -674,6 +674,59 @@ def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C, levels, onepass):
     torch.testing.assert_close(dbet.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * gs)
 
 
+@pytest.mark.parametrize("onepass", [1, 0])
+@pytest.mark.parametrize("levels", [[(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)], [(6, 6), (3, 3), (1, 1)]])
+def test_groupnorm_bwd_pair_equals_two_launches(gpu_device, levels, onepass):
+    """kd6d_gn_relu_bwd_pair: the two tower layers' GroupNorm backwards in one launch give what two launches give
+    (dx bit for bit -- each element is computed by the same code from the same sums; dgamma / dbeta to atomic-order
+    noise); with gn.onepass = 0 the entry falls back to two launch pairs."""
+    ops = _ops()
+    dev = gpu_device
+    _option("gn.onepass", onepass)
+    B, G, C = 4, 32, 128
+    hw = [h * w for (h, w) in levels]
+    rows = B * sum(hw)
+    g = torch.Generator().manual_seed(11)
+    bf = torch.bfloat16
+
+    def make():
+        x = (torch.randn(rows, C, generator=g) * 1.5 + 0.2).to(dev)                     # fp32 raw conv output
+        dz = torch.randn(rows, C, generator=g).to(bf).to(dev)
+        gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(C, generator=g) * 0.2).to(dev)
+        stats = torch.empty(len(levels) * B * G * 2, device=dev)
+        y = torch.empty(rows, C, dtype=bf, device=dev)
+        ops.gn_relu_fwd(x, y, hw, B, G, gamma, beta, 1e-5, stats)
+        return x, dz, gamma, beta, stats
+
+    sets = [make(), make()]
+    nws = ops.gn_bwd_workspace_floats(len(levels), B, G)
+
+    def run(pair):
+        outs, items = [], []
+        for (x, dz, gamma, beta, stats) in sets:
+            dx = torch.empty(rows, C, dtype=bf, device=dev)
+            dgam = torch.zeros(C, device=dev); dbet = torch.zeros(C, device=dev)
+            gsum = torch.empty(nws, device=dev)
+            outs.append((dx, dgam, dbet))
+            items.append((x, dz, dx, gamma, beta, stats, gsum, dgam, dbet))
+        if pair:
+            ops.gn_relu_bwd_pair(items, hw, B, G)
+        else:
+            for (x, dz, dx, gamma, beta, stats, gsum, dgam, dbet) in items:
+                ops.gn_relu_bwd(x, dz, dx, hw, B, G, gamma, beta, stats, gsum, dgam, dbet)
+        torch.cuda.synchronize()
+        return outs
+
+    want, got = run(False), run(True)
+    assert ops.lib.kd6d_barrier_timeouts() == 0
+    for (dx_w, dg_w, db_w), (dx_g, dg_g, db_g) in zip(want, got):
+        torch.testing.assert_close(dx_g.float(), dx_w.float(), rtol=0, atol=2e-2 * float(dx_w.float().abs().max()) * 2 ** -7)
+        assert float((dx_g.float() - dx_w.float()).abs().gt(0).float().mean()) < 1e-2      # group sums: atomic order
+        torch.testing.assert_close(dg_g, dg_w, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(db_g, db_w, rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pool_upsample_eltwise(gpu_device, dtype):
     ops = _ops()
