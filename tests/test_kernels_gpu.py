@@ -678,8 +678,8 @@ def test_groupnorm_relu_fwd_bwd(gpu_device, dtype, xf32, C, levels, onepass):
 @pytest.mark.parametrize("levels", [[(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)], [(6, 6), (3, 3), (1, 1)]])
 def test_groupnorm_bwd_pair_equals_two_launches(gpu_device, levels, onepass):
     """kd6d_gn_relu_bwd_pair: the two tower layers' GroupNorm backwards in one launch give what two launches give
-    (dx bit for bit -- each element is computed by the same code from the same sums; dgamma / dbeta to atomic-order
-    noise); with gn.onepass = 0 the entry falls back to two launch pairs."""
+    (dx to one bf16 ulp on a few elements -- same code, group sums differ by atomic order; dgamma / dbeta to
+    atomic-order noise); with gn.onepass = 0 the entry falls back to two launch pairs."""
     ops = _ops()
     dev = gpu_device
     _option("gn.onepass", onepass)
@@ -721,8 +721,10 @@ def test_groupnorm_bwd_pair_equals_two_launches(gpu_device, levels, onepass):
     want, got = run(False), run(True)
     assert ops.lib.kd6d_barrier_timeouts() == 0
     for (dx_w, dg_w, db_w), (dx_g, dg_g, db_g) in zip(want, got):
-        torch.testing.assert_close(dx_g.float(), dx_w.float(), rtol=0, atol=2e-2 * float(dx_w.float().abs().max()) * 2 ** -7)
-        assert float((dx_g.float() - dx_w.float()).abs().gt(0).float().mean()) < 1e-2      # group sums: atomic order
+        # the group sums are accumulated with float atomics: an element may land on the neighbouring bf16 value
+        diff = (dx_g.float() - dx_w.float()).abs()
+        assert bool((diff <= dx_w.float().abs() * 2 ** -7 + 1e-6).all())
+        assert float(diff.gt(0).float().mean()) < 1e-2
         torch.testing.assert_close(dg_g, dg_w, rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(db_g, db_w, rtol=1e-4, atol=1e-3)
 

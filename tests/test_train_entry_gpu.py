@@ -99,7 +99,9 @@ def test_resume_from_latest_pth(gpu_device, tmp_path):
     # as a fraction of lr (2.5e-4 here) on a few hundred of 2.3 M elements
     lr = opt.param_groups[0]["lr"]
     d = (model2.net.store.params - model.net.store.params).abs()
-    assert float(d.max()) <= 0.2 * lr and float((d > 1e-6).float().mean()) < 1e-3, (float(d.max()), lr)
+    # (measured: max 4.5e-5 = 0.07 lr; 0.1-0.8 % of the elements above 1e-6, run to run; a lost optimiser state moves
+    #  every element by ~lr)
+    assert float(d.max()) <= 0.2 * lr and float((d > 1e-6).float().mean()) < 2e-2, (float(d.max()), lr)
     # the moments after step 4: a lost or stale state would differ by 0.9 * m3 (relative O(1)); what is left between two
     # runs of the same step is summation-order noise (measured: 2 of 2.24 M elements off by 1.3e-6 at |m| < 3e-4)
     for a, b in ((opt2.exp_avg, opt.exp_avg), (opt2.exp_avg_sq, opt.exp_avg_sq)):
