@@ -236,8 +236,8 @@ int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, 
  * adds its partial sums, meets the others at an in-kernel barrier on `counter` and finishes dx -- one read of x
  * and dz instead of two, one launch instead of two.  By default only tensors of up to 65536 granules take it
  * (<= 128 workgroups: there the barrier is cheaper than a launch; beyond, exchanging the sums costs more than the
- * second read -- KD6D_BN_ONEPASS_MAX=<granules> moves the limit).  counter == NULL, a larger tensor or
- * KD6D_BN_ONEPASS=0: the reduce + apply pair above.  kd6d_barrier_timeouts(): number of barrier waits that gave up (must stay 0). */
+ * second read -- option bn.onepass_max = <granules> moves the limit).  counter == NULL, a larger tensor or
+ * option bn.onepass = 0: the reduce + apply pair above.  kd6d_barrier_timeouts(): number of barrier waits that gave up (must stay 0). */
 int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
                       const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
                       float* sum_dy, float* sum_dy_xhat, unsigned int* counter, float* dgamma, float* dbeta,
@@ -249,7 +249,7 @@ int kd6d_barrier_timeouts(void);
  * (level, image, group) = RAW sums {sum x, sum x^2} (mean/rstd are derived by the consumers, which is
  * why the backward takes eps too); gsum_ws (backward): 2*nseg*batch*groups floats of sums followed by
  * nseg*batch 32-bit barrier counters -- the backward is ONE launch whose workgroups of a (level, image) meet at
- * an in-kernel barrier (see kd6d_bn_train_bwd; KD6D_GN_ONEPASS=0: the reduce + apply pair).
+ * an in-kernel barrier (see kd6d_bn_train_bwd; option gn.onepass = 0: the reduce + apply pair).
  * flags: bit 0 (KD6D_GN_STATS_READY) -- stats were already accumulated by kd6d_conv2d_fwd(..., stats,
  * groups): skip the reduction pass; bit 1 (KD6D_GN_WS_ZEROED) -- the caller zeroed stats (fwd, when not
  * ready) / gsum_ws (bwd) itself (e.g. one memset of a whole scratch arena per step): skip the memset node.

@@ -1731,7 +1731,7 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
     DISPATCH_TTX(dtype, x_f32, gcap = (gn_onepass_capacity<T_, TX_>()));
     for (int s = 0; s < nseg; ++s) gmax = g1.cps[s] > gmax ? g1.cps[s] : gmax;
     KD6D_CHECK_ARG(gcap >= 2 * gmax, "kd6d_gn_relu_bwd: a level of %d row chunks does not fit the %d resident workgroups "
-                   "(set KD6D_GN_ONEPASS=0)", gmax, gcap);
+                   "(set option gn.onepass = 0)", gmax, gcap);
     unsigned int* counters = reinterpret_cast<unsigned int*>(gsum_ws + 2 * (size_t)nseg * batch * groups);
     if (!(flags & KD6D_GN_WS_ZEROED) &&
         hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)nseg * batch, st) != hipSuccess) {
