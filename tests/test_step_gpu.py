@@ -413,6 +413,44 @@ def test_pipeline_restarts_after_flush(gpu_device):
     assert got[2] > 0, "the KD term must be active in this test"
 
 
+def test_replayed_step_draws_new_sampling_keys(gpu_device):
+    """Without pinned keys the replayed step draws its SSC sampling keys on the device from (seed, step counter, cell):
+    every replay sees new keys in [0, 1), the same seed reproduces the sequence, and the step stays finite."""
+    from kd6d.graph import GraphedKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import make_batch
+    dev = gpu_device
+    teacher = build("darknet53", "bf16", 2, dev, [1.0] + [-6.0] * 14).eval()
+    images, targets = make_batch(2, 31, crop=64)
+    batch = (ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev))
+
+    def run():
+        torch.manual_seed(1234)
+        student = build("darknet_tiny_h", "bf16", 1, dev).train()
+        opt = FusedClipAdamW(student, lr=1e-4)
+        gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=False)
+        keys, losses = [], []
+        for _ in range(4):
+            ld = gs(*batch)
+            torch.cuda.synchronize()
+            (kb,) = list(student.loss_evaluator._keys.values())
+            keys.append(kb.clone())
+            losses.append([float(ld[k]) for k in ("loss_cls", "loss_reg", "loss_kd")])
+        return keys, np.array(losses)
+
+    keys, losses = run()
+    assert np.isfinite(losses).all()
+    for k in keys:
+        assert float(k.min()) >= 0.0 and float(k.max()) < 1.0 and 0.3 < float(k.mean()) < 0.7
+    for a, b in zip(keys[:-1], keys[1:]):
+        assert float((a == b).float().mean()) < 1e-2
+    keys2, _ = run()
+    for a, b in zip(keys, keys2):
+        assert torch.equal(a, b)
+
+
 def test_eval_between_graph_replays_sees_current_weights(gpu_device):
     """A replayed optimiser graph changes the weights without passing through Python: the eval-mode BatchNorm
     scale/shift cached by the previous validation must not survive it (every VAL_FREQ steps train_kd.py validates
