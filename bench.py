@@ -10,14 +10,25 @@ One step = teacher (Darknet-53, frozen, eval) forward + teacher cell selection +
 synthetic LINEMOD-shaped batch (640x480 frame geometry, 256x256 DZI crops: what the reference
 actually feeds the network), B = 16 images per GPU, inputs resident in HBM.
 
+`python bench.py --gpus N` without WORLD_SIZE in the environment launches its own N ranks (one child process per
+GPU, started before this process makes any GPU call; rank 0's line is passed through, a failing rank fails the run).
+
 The single JSON line carries, besides the contract fields:
-  roofline     -- dominant kernel = the implicit-GEMM convolution (all launches of
-                  kd6d_conv2d_{fwd,dgrad,wgrad} in a step): algorithmic FLOPs (2*MAC on the
-                  reference's channel counts) / summed launch durations measured with HIP events
-                  on the launch stream in instrumented steps after the timed region
-                  (DESIGN.md "Measurement"); peak = 2.5 PFLOP/s dense bf16 MFMA.
+  roofline     -- dominant kernel family = the implicit-GEMM convolutions (kd6d_conv2d_{fwd,dgrad,wgrad} and the
+                  grouped weight gradient): `achieved` = algorithmic conv FLOP of a step (SURVEY.md 8(d), 2*MAC on the
+                  reference's channel counts) / WALL ms_per_step of the timed, hipGraph-replayed steps, per GPU;
+                  peak = 2.5 PFLOP/s dense bf16 MFMA.  `eager_launch_events` keeps the per-launch HIP-event figures of
+                  a few eagerly launched single-stream steps after the timed region (a different schedule: per-family
+                  kernel efficiency, not step time).  `traffic` = HBM bytes of the conv family per step from the
+                  rocprofv3 PMC passes committed under profiles/ (tools/pmc_traffic.sh), null when that file does not
+                  describe the configuration being run.
   cpu_baseline -- oracle/kd_step_ref.py (pure-torch fp32 port of the reference step, validated
                   against the imported reference) timed on this host's cores, rank 0, N=1 only.
+  secondary    -- (N=1, default workload only) 20-step timings of the other BASELINE configurations, each run by this
+                  same script in a child process AFTER the headline's timed region: config 4's per-GPU shard
+                  (--workload linemod13), full 480x640 frames (--frame full640), strictly sequential steps
+                  (--no-pipeline) and the dense 16-D OT of config 5 (--workload dense16d).  The headline does not
+                  depend on them: a failing child is reported inside its entry.
 """
 import argparse
 import json
@@ -59,6 +70,9 @@ def parse():
     p.add_argument("--opt", action="append", default=[],
                    help="kernel-selection option name=value (kd6d_set_option, include/kd6d.h): tuning aid for A/B runs")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` timings (child runs of the other configs)")
+    p.add_argument("--no-launch-events", action="store_true",
+                   help="skip the eagerly launched, HIP-event-instrumented steps behind roofline.eager_launch_events")
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--no-pipeline", action="store_true",
                    help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
@@ -104,8 +118,112 @@ class _StdoutToStderr:
         print(line, flush=True)
 
 
+def _gpu_numa_cpus(local_rank, world):
+    """CPUs next to GPU `local_rank`, found WITHOUT touching the GPU: the kfd topology in sysfs lists the GPU nodes in
+    HIP's device order and, per node, an io_link to its host NUMA node.  Falls back to an even split of the CPUs this
+    process may run on."""
+    allowed = sorted(os.sched_getaffinity(0))
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            with open(os.path.join(base, n, "properties")) as f:
+                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+            if int(props.get("simd_count", 0)) > 0:
+                gpus.append(n)
+        node = gpus[local_rank]
+        cpu_node = None
+        links = os.path.join(base, node, "io_links")
+        for l in sorted(os.listdir(links), key=int):
+            with open(os.path.join(links, l, "properties")) as f:
+                lp = dict(x.split()[:2] for x in f if len(x.split()) >= 2)
+            with open(os.path.join(base, lp["node_to"], "properties")) as f:
+                tp = dict(x.split()[:2] for x in f if len(x.split()) >= 2)
+            if int(tp.get("cpu_cores_count", 0)) > 0:
+                cpu_node = int(lp["node_to"])
+                break
+        with open("/sys/devices/system/node/node%d/cpulist" % cpu_node) as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        near = [c for c in allowed if c in cpus]
+        if near:
+            return near
+    except (OSError, ValueError, KeyError, IndexError, TypeError):
+        pass
+    per = max(len(allowed) // max(world, 1), 1)
+    return allowed[local_rank * per:(local_rank + 1) * per] or allowed
+
+
+def pin_host_thread(local_rank, world):
+    """Eight ranks on one host each issue ~1 ms of launches per 3-ms step: keep every rank's host thread on the
+    cores of its GPU's NUMA node.  Called before any GPU call; a single rank is left alone."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = _gpu_numa_cpus(local_rank, world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return len(cpus)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as child processes (env RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*, what torch.distributed.run would set) BEFORE this process makes any GPU call,
+    pass rank 0's JSON line through, and exit with the first non-zero return code.  The reference does the same through
+    `torch.distributed.launch` (train.sh; train_kd.py:43-51 reads WORLD_SIZE / --local_rank)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    out0 = b""
+    import select
+    while pending:
+        # drain rank 0's stdout so that it never blocks on a full pipe
+        if procs[0].stdout is not None and 0 in pending:
+            ready, _, _ = select.select([procs[0].stdout], [], [], 0.2)
+            if ready:
+                chunk = os.read(procs[0].stdout.fileno(), 1 << 16)
+                out0 += chunk
+        else:
+            time.sleep(0.2)
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                 # the others would wait for the dead rank in a collective
+                    procs[q].terminate()
+    out0 += procs[0].stdout.read() or b""
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    world_env = int(os.environ.get("WORLD_SIZE", 1))
+    if world_env > 1:
+        n_vis = torch.cuda.device_count()          # (does not initialise the GPU)
+        if n_vis < world_env:
+            raise SystemExit("bench.py: %d GPUs needed, %d visible (rank %s)" % (world_env, n_vis, os.environ.get("RANK", "0")))
+    pinned = pin_host_thread(int(os.environ.get("LOCAL_RANK", 0)), world_env)
     out_fd = _StdoutToStderr()
     if args.workload == "dense16d":
         return bench_dense(args, out_fd)
@@ -118,8 +236,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the kd6d step has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -243,7 +360,7 @@ def main():
 
     # ---- roofline leg: per-launch HIP-event timing of every conv launch, in instrumented steps that
     # every rank runs (the step contains the gradient all-reduce) but only rank 0 records ----
-    n_instr = 3
+    n_instr = 0 if args.no_launch_events else 3
     if rank == 0:
         ops.profile_begin()
     for i in range(n_instr):
@@ -254,7 +371,7 @@ def main():
     rec = ops.profile_end() if rank == 0 else []
 
     out = None
-    if rank == 0 and args.layer_table:
+    if rank == 0 and args.layer_table and n_instr:
         write_layer_table(args.layer_table, rec, n_instr)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -288,16 +405,18 @@ def main():
                 "basis": "algorithmic conv FLOP per step / wall ms_per_step of the timed hipGraph-replayed steps, per GPU",
                 "achieved": wall_tflops / 1e12 if wall_tflops else achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": (wall_tflops if wall_tflops else achieved) / peak,
-                "flop_per_step": flop_img * B if flop_img else tot_flop / n_instr,
+                "flop_per_step": flop_img * B if flop_img else tot_flop / max(n_instr, 1),
                 "traffic": traffic, "traffic_unit": "HBM bytes per step, conv family (PMC, profiles/r02_conv_hbm_traffic.json)",
                 "eager_launch_events": {
                     "note": "HIP events around every conv launch of %d eagerly launched single-stream steps after the "
                             "timed region; NOT the timed schedule" % n_instr,
-                    "tflops": achieved / 1e12, "frac": achieved / peak, "launches_per_step": len(conv) // n_instr,
-                    "avg_launch_us": 1e3 * tot_ms / max(len(conv), 1), "kernel_ms_per_step_serial": tot_ms / n_instr,
-                    "by_kind": {k: {"launches_per_step": v[0] // n_instr,
+                    "tflops": achieved / 1e12, "frac": achieved / peak, "launches_per_step": len(conv) // max(n_instr, 1),
+                    "avg_launch_us": 1e3 * tot_ms / max(len(conv), 1), "kernel_ms_per_step_serial": tot_ms / max(n_instr, 1),
+                    "by_kind": {k: {"launches_per_step": v[0] // max(n_instr, 1),
                                     "tflops": v[1] / (v[2] * 1e-3) / 1e12 if v[2] else 0,
-                                    "kernel_ms_per_step_serial": v[2] / n_instr} for k, v in by_kind.items()}}}
+                                    "kernel_ms_per_step_serial": v[2] / max(n_instr, 1)} for k, v in by_kind.items()}}}
+        if n_instr == 0:
+            roof.pop("eager_launch_events")
         out = {"metric": "KD train-step images/sec (teacher+student fwd + OT loss + bwd + AdamW)", "value": value,
                "unit": "images/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": per_rank_ms, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
@@ -318,6 +437,12 @@ def main():
         # ---- CPU baseline leg (oracle = port of the reference step), rank 0, N=1 only ----
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, B, full)
+        if pinned:
+            out["config"]["host_cpus_per_rank"] = pinned
+        default_run = (args.workload == "ape" and not full and not args.no_pipeline and not args.no_graph
+                       and args.student == "darknet_tiny_h" and args.precision == "bf16" and not args.opt)
+        if world == 1 and default_run and not args.no_secondary:
+            out["secondary"] = secondary_runs(args)
     if use_pg:
         dist.barrier()
         D.shutdown_exchange()
@@ -404,6 +529,44 @@ def bench_dense(args, out_fd):
                      "unit": "T lane-op/s (fp32 vector, FMA = 1)", "frac": head["frac_of_fp32_vector_peak"], "traffic": None,
                      "basis": "(2D+8) lane-ops per (row, column) pair x pairs per image / wall time"},
         "all_blurs": results, "finite": all(r_["finite"] for r_ in results)}))
+
+
+SECONDARY = [          # (name, BASELINE.json config it stands for, extra flags)
+    ("linemod13", "config 4 per-GPU shard: 13 LINEMOD classes mixed per batch, darknet53 -> darknet_tiny", ["--workload", "linemod13"]),
+    ("full640", "S640 variant of config 2: (16,3,480,640) full frames", ["--frame", "full640"]),
+    ("no_pipeline", "config 2, strictly sequential steps (teacher and student of the SAME batch in one step)", ["--no-pipeline"]),
+    ("dense16d", "config 5: dense 16-D OT over a 128x128 cell grid", ["--workload", "dense16d"]),
+]
+
+
+def secondary_runs(args):
+    """The other BASELINE configurations, 20 timed steps each, run by this script in child processes (one at a time,
+    after the headline's timed region; this process keeps its GPU memory but launches nothing meanwhile)."""
+    import subprocess
+    res = []
+    for name, what, flags in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "20", "--warmup", "5", "--batch",
+               str(args.batch), "--no-cpu-baseline", "--no-secondary", "--no-launch-events"] + flags
+        entry = {"name": name, "what": what, "flags": " ".join(flags)}
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                entry.update(ok=False, rc=r.returncode, error=(r.stderr or "")[-400:])
+            else:
+                d = json.loads(line[-1])
+                entry.update(ok=True, value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], steps=d["steps"],
+                             dtype=d["dtype"], workload=d["config"]["workload"], finite=d.get("finite"),
+                             roofline={k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")})
+                if "all_blurs" in d:
+                    entry["all_blurs"] = [{k: b[k] for k in ("blur", "ms_per_image", "images_per_s",
+                                                               "frac_of_fp32_vector_peak")} for b in d["all_blurs"]]
+        except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
+            entry.update(ok=False, error=repr(e)[:400])
+        entry["wall_s"] = time.perf_counter() - t0
+        res.append(entry)
+    return res
 
 
 def write_layer_table(path, rec, n_instr):

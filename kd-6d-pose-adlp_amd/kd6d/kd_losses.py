@@ -281,7 +281,13 @@ class KDLoss:
         self.ctx = None
         self._ws = {}
         self._keys = {}
-        self.seed = torch.initial_seed()      # device-side sampling keys: reproducible from torch.manual_seed
+        # device-side sampling keys: reproducible from torch.manual_seed.  The key of a cell is a hash of (seed, step
+        # counter, cell index) and train_kd.py seeds every rank alike, so the rank is mixed in: data-parallel ranks
+        # must not draw the same key field every step (the reference's torch.randperm runs from one seed on every rank
+        # too, but consumes the generator per ground truth of ITS shard, so its ranks decorrelate); the constant also
+        # keeps (seed 0, step 0, cell 0) from hashing the all-zero state
+        from .libs.distributed import get_rank
+        self.seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (get_rank() + 1)) & 0xFFFFFFFFFFFFFFFF
         self.anchor_sizes, self.anchor_strides = ANCHOR_SIZES, ANCHOR_STRIDES      # configs/ape.yaml:3-4
 
     def workspaces(self, batch, device):

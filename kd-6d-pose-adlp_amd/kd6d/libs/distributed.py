@@ -66,6 +66,16 @@ def init_exchange():
     if _comm is not None or not torch.cuda.is_available():
         return _route
     from .._lib import lib
+    # Agree BEFORE the blocking collective: ncclCommInitRank waits for every rank, so a rank that cannot take part
+    # (no librccl, no current device) must be known to all of them first -- it would otherwise fall through to the
+    # torch route while the others wait for it inside the init.
+    able = 1 if lib.kd6d_comm_version() >= 0 else 0          # dlopen + symbol resolution, no communication
+    try:
+        torch.cuda.current_device()
+    except (RuntimeError, AssertionError):
+        able = 0
+    if not _all_agree(able):
+        return _route            # some rank has no librccl / device: every rank stays on torch.distributed
     ident = ctypes.create_string_buffer(128)
     ok = 1
     if get_rank() == 0 and lib.kd6d_comm_unique_id(ident) != 0:
@@ -73,18 +83,33 @@ def init_exchange():
     box = [ident.raw if ok else None]
     dist.broadcast_object_list(box, src=0)
     if box[0] is None:
-        return _route            # rank 0 has no librccl: every rank stays on torch.distributed
+        return _route            # rank 0 could not create the id: every rank stays on torch.distributed
     handle = ctypes.c_void_p()
     rc = lib.kd6d_comm_init(ctypes.byref(handle), get_rank(), dist.get_world_size(), box[0])
-    flags = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda")
-    dist.all_reduce(flags, op=dist.ReduceOp.MIN)       # all ranks take the same route
-    if int(flags.item()) == 1:
+    if _all_agree(1 if rc == 0 else 0):
         _comm = handle
         v = lib.kd6d_comm_version()
         _route = "kd6d_comm (librccl %d.%d.%d)" % (v // 10000, (v // 100) % 100, v % 100)
     elif rc == 0:
         lib.kd6d_comm_destroy(handle)
     return _route
+
+
+def _all_agree(flag):
+    """MIN over ranks of a 0 / 1 flag through torch.distributed (the rendezvous route, always available here)."""
+    t = torch.tensor([int(flag)], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def max_over_ranks(value):
+    """MAX over ranks of a small non-negative integer (e.g. the barrier-timeout count): every rank gets the same
+    answer, so a decision taken on it is collective."""
+    if get_world_size() <= 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def shutdown_exchange():

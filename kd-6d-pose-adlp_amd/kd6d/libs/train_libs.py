@@ -62,13 +62,46 @@ def build_model(cfg, posemodule, device="cuda"):
         chkpt = torch.load(latest, map_location="cpu", weights_only=False)
         total_steps = chkpt["steps"]
         model.load_state_dict(chkpt["model"])
+        # The optimiser and the scheduler are resumed independently.  An `optim` entry this optimiser cannot take
+        # (e.g. one written by the reference's torch.optim.AdamW: per-tensor moments, not the flat buffers) only
+        # restarts the Adam moments; the OneCycle schedule still continues from step N -- the reference's `sched`
+        # entry is a plain torch scheduler state and loads as is, and a missing / unusable one is replaced by
+        # fast-forwarding the fresh scheduler to `total_steps`.
+        resumed = []
         try:
             optimizer.load_state_dict(chkpt["optim"])
+            resumed.append("optimizer")
+        except (ValueError, KeyError, TypeError) as e:
+            print("optimiser state of %s NOT resumed (Adam moments restart): %s" % (latest, e))
+        try:
             scheduler.load_state_dict(chkpt["sched"])
-            print("Weights, optimzer, scheduler are loaded from %s, starting from step %d" % (latest, total_steps))
-        except ValueError as e:      # e.g. an `optim` entry written by the reference's torch.optim.AdamW
-            print("Weights are loaded from %s; optimiser / scheduler state NOT resumed: %s" % (latest, e))
+            if int(scheduler.last_epoch) != int(total_steps):
+                raise ValueError("scheduler state is at step %d, checkpoint at %d" % (scheduler.last_epoch, total_steps))
+            resumed.append("scheduler")
+        except (ValueError, KeyError, TypeError, AttributeError) as e:
+            print("scheduler state of %s NOT loaded (%s): fast-forwarding OneCycle to step %d" % (latest, e, total_steps))
+            scheduler = _fast_forward_scheduler(optimizer, base_lr, cfg["SOLVER"]["MAX_ITER"] + 100, total_steps)
+        lr_now = scheduler.get_last_lr()[0]
+        for g in optimizer.param_groups:
+            g["lr"] = lr_now
+        print("Weights%s are loaded from %s, starting from step %d (lr %.6g)" % (
+            "".join(", " + r for r in resumed), latest, total_steps, lr_now))
     return model, optimizer, scheduler, total_steps
+
+
+def _fast_forward_scheduler(optimizer, base_lr, total, steps):
+    """A fresh OneCycleLR (libs/train_libs.py:118-120) advanced to `steps` without touching the weights."""
+    import warnings
+    for g in optimizer.param_groups:          # OneCycleLR's constructor derives initial_lr / max_lr / min_lr again
+        for k in ("initial_lr", "max_lr", "min_lr"):
+            g.pop(k, None)
+    sched = optim.lr_scheduler.OneCycleLR(optimizer, base_lr, total, pct_start=0.05, cycle_momentum=False,
+                                          anneal_strategy="linear")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")       # "lr_scheduler.step() before optimizer.step()": intended here
+        for _ in range(int(steps)):
+            sched.step()
+    return sched
 
 
 def build_model_teacher(cfg, posemodule, device):

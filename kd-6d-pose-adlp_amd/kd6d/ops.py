@@ -491,9 +491,10 @@ class WgradGroup:
     def __init__(self, n_workgroups):
         self.n_workgroups = int(n_workgroups)
         self.items, self.flops = [], 0
-        self._key = None
-        self._plan = self._slab = self._info = None
-        self._keep = None
+        # one (plan, slab, info, tensors) per distinct set of tensors, kept for the life of the group: a captured
+        # hipGraph replays the device pointers of the plan it was captured with, so a later eager launch with other
+        # buffers (another batch size on the same network) must not free or overwrite it
+        self._plans = {}
 
     def add(self, geom, x, dy, dw, dbias=None, flops=0):
         assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
@@ -507,6 +508,10 @@ class WgradGroup:
         return len(self.items)
 
     def _build(self, device):
+        # the plan travels host -> device with a pageable copy and the slab is allocated: neither may happen inside a
+        # stream capture (the engine's eager warm-up steps run the same launch first, so the capture finds the plan)
+        assert not torch.cuda.is_current_stream_capturing(), \
+            "WgradGroup: first launch of a new tensor set inside a graph capture (run one eager warm-up step first)"
         n = len(self.items)
         arr = (_lib.WgradItem * n)()
         for i, (g, x, dy, dw, db) in enumerate(self.items):
@@ -522,23 +527,26 @@ class WgradGroup:
                                        int(nbytes), info)
         if rc < 0:
             check(int(rc), "kd6d_wgrad_group_plan")
-        self._plan = host.to(device)
         slab_floats = int(info[2]) + (int(info[3]) << 31)
-        if self._slab is None or self._slab.numel() < slab_floats:
-            self._slab = torch.empty(slab_floats, dtype=torch.float32, device=device)
-        self._info = (int(info[0]), int(info[1]))
-        self._keep = list(self.items)
+        # allocated on the default stream: the caching allocator then never hands the blocks to another stream's
+        # tensors while a side stream (where the launch runs) still uses them
+        with torch.cuda.stream(torch.cuda.default_stream(device)):
+            plan = host.to(device)
+            slab = torch.empty(slab_floats, dtype=torch.float32, device=device)
+        torch.cuda.current_stream().wait_stream(torch.cuda.default_stream(device))
+        return dict(plan=plan, slab=slab, info=(int(info[0]), int(info[1])), keep=list(self.items))
 
     def launch(self):
         """Enqueue on the current stream; clears the collected items."""
         if not self.items:
             return
-        key = tuple((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), g.rows_out)
-                    for g, x, dy, dw, db in self.items)
-        if key != self._key:
-            self._build(self.items[0][1].device)
-            self._key = key
+        key = (self.n_workgroups,) + tuple(
+            (x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), g.rows_out)
+            for g, x, dy, dw, db in self.items)
+        ent = self._plans.get(key)
+        if ent is None:
+            ent = self._plans[key] = self._build(self.items[0][1].device)
         with _Timed("conv_wgrad", self.flops, self.items[0][0]):
-            check(lib.kd6d_wgrad_group_launch(_ptr(self._plan), self._info[0], self._info[1], _ptr(self._slab),
+            check(lib.kd6d_wgrad_group_launch(_ptr(ent["plan"]), ent["info"][0], ent["info"][1], _ptr(ent["slab"]),
                                               _stream()), "kd6d_wgrad_group_launch")
         self.items, self.flops = [], 0

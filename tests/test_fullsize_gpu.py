@@ -48,7 +48,8 @@ def _record(key, value):
 # ---------------------------------------------------------------------------------------------------------
 def _layers():
     import step_layers as BC
-    return [("teacher",) + l for l in BC.TEACHER] + [("student",) + l for l in BC.STUDENT]
+    return ([("teacher",) + l for l in BC.TEACHER] + [("student",) + l for l in BC.STUDENT]
+            + [("teacher",) + l for l in BC.TEACHER_640] + [("student",) + l for l in BC.STUDENT_640])
 
 
 LAYERS = _layers()
@@ -79,6 +80,24 @@ def test_conv_layer_at_benchmark_shape(gpu_device, layer):
     for gl, ref in zip(unpack_levels(y.cpu(), B, geom.levels_out), refs):
         torch.testing.assert_close(gl, ref, rtol=2e-4, atol=2e-4)
     if net != "student":
+        # the epilogue the frozen teacher actually runs (backbone/common.py:316-324 folded, darknet53.py:20-58):
+        # per-channel scale / shift, LeakyReLU(0.1), the DarkUnit's residual add on the 3x3 layers, bf16 store
+        # (the 16-byte lane-pair-swap store path and the 16-byte residual load)
+        sc = (torch.rand(cout, generator=g) + 0.5)
+        sh = torch.randn(cout, generator=g) * 0.1
+        res = None
+        if k == 3 and stride == 1 and len(levels) == 1 and cin * 2 == cout:
+            res = [round_to(torch.randn(B, cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
+        yb = ops.conv2d_fwd(geom, xp, w_to_krsc(w, dtype).to(dev), ch_scale=sc.to(dev), ch_shift=sh.to(dev),
+                            act=ops.ACT_LEAKY, residual=None if res is None else pack_levels(res, dtype).to(dev),
+                            workspace=ws)
+        torch.cuda.synchronize()
+        assert yb.dtype == dtype
+        for li, (gl, ref) in enumerate(zip(unpack_levels(yb.float().cpu(), B, geom.levels_out), refs)):
+            want = F.leaky_relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.1)
+            if res is not None:
+                want = want + res[li]
+            torch.testing.assert_close(gl, want, rtol=1.2e-2, atol=1.2e-2)
         return
     dys = [round_to(torch.randn(B, cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
     dyp = pack_levels(dys, dtype).to(dev)
@@ -144,6 +163,23 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
     """BASELINE config 2 (Ape, 53 -> tiny_h) and config 4's per-GPU shard (the 13 LINEMOD classes mixed in one batch,
     53 -> tiny), B = 16, 256x256, through GraphedKDStep(pipeline=True): losses, global and per-tensor gradient norms,
     gradient direction, the first fused clip + AdamW update and the losses of the following step vs the oracle."""
+    _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full=False)
+
+
+_ORACLE_640 = {}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_frame_640x480_pipelined_graph_vs_oracle(gpu_device, precision):
+    """The S640 variant of config 2 ((16,3,480,640) full frames, identity bbox_trans -- the geometry of
+    /root/reference/configs/ape.yaml:18-19, what `bench.py --frame full640` times): pyramid levels 60x80 / 30x40 /
+    15x20 / 8x10 (/ 4x5), 6380 student and 6400 teacher cells per image, odd map sizes (15 -> 8 -> 4 rows).  Same
+    checks as the 256x256 case for the first step; the oracle's step (one per process, shared by both precisions) is
+    not repeated for a second batch."""
+    _pipelined_graph_vs_oracle(gpu_device, precision, "darknet_tiny_h", False, full=True)
+
+
+def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     from kd6d import ops
     from kd6d.graph import GraphedKDStep
     from kd6d.kd_losses import PackedTargets
@@ -160,7 +196,7 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 10100, pct_start=0.05, cycle_momentum=False,
                                                 anneal_strategy="linear")
     ref = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0, teacher_cls_bias=BIAS)
-    levels = [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
+    levels = [(60, 80), (30, 40), (15, 20), (8, 10)] if full else [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
     cells = sum(h * w for h, w in levels)
     counts = [h * w for h, w in levels]
     keys_ref = torch.rand(B * cells, generator=torch.Generator().manual_seed(17))
@@ -172,7 +208,7 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
 
     cpu_batches, batches = [], []
     for i in range(2):
-        images, targets = make_batch(B, 41 + i, crop=crop, mixed_classes=mixed)
+        images, targets = make_batch(B, 41 + i, crop=crop, mixed_classes=mixed, full_frame=full)
         cpu_batches.append((images.tensors, [t.as_dict() for t in targets]))
         batches.append((ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)))
     if mixed:
@@ -186,8 +222,13 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
     got1 = {k: float(v) for k, v in ld.items()}
     gn1 = float(opt.grad_norm())
     # oracle, step 1
-    res1 = ref.step(*cpu_batches[0], choose=choose)
-    ref_grads = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
+    if full and "res1" in _ORACLE_640:
+        res1, ref_grads = _ORACLE_640["res1"], _ORACLE_640["grads"]
+    else:
+        res1 = ref.step(*cpu_batches[0], choose=choose)
+        ref_grads = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
+        if full:
+            _ORACLE_640.update(res1=res1, grads=ref_grads)
     clip = min(1.0, 1.0 / (res1["grad_norm"] + 1e-6))
     rep = _grad_report(student, ref_grads, clip, res1["grad_norm"])
     rep.update({"d_" + k: abs(got1[k] - res1[k]) / max(abs(res1[k]), 1e-6) for k in got1},
@@ -209,10 +250,12 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
     ld2 = gs(*batches[0])
     torch.cuda.synchronize()
     got2 = {k: float(v) for k, v in ld2.items()}
-    res2 = ref.step(*cpu_batches[1], choose=choose)
-    rep.update({"d2_" + k: abs(got2[k] - res2[k]) / max(abs(res2[k]), 1e-6) for k in got2})
+    assert all(v == v and abs(v) != float("inf") for v in got2.values()), got2
+    if not full:
+        res2 = ref.step(*cpu_batches[1], choose=choose)
+        rep.update({"d2_" + k: abs(got2[k] - res2[k]) / max(abs(res2[k]), 1e-6) for k in got2})
     rep["barrier_timeouts"] = int(ops.lib.kd6d_barrier_timeouts())
-    _record("%s_%s" % (arch + ("_mixed13" if mixed else ""), precision), rep)
+    _record("%s_%s" % (arch + ("_mixed13" if mixed else "") + ("_full640" if full else ""), precision), rep)
     print("[fullsize %s %s] %s" % (arch, precision, json.dumps(rep, default=str)))
 
     assert rep["barrier_timeouts"] == 0
@@ -224,7 +267,8 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
     assert rep["worst_norm_1k"] <= tol["worst1k"], rep
     assert 1.0 - rep["cosine"] <= tol["cos"], rep
     assert rep["sign_agreement"] >= tol["sign"], rep
-    assert rep["d2_loss_cls"] <= tol["loss2"] and rep["d2_loss_reg"] <= tol["loss2"], rep
+    if not full:
+        assert rep["d2_loss_cls"] <= tol["loss2"] and rep["d2_loss_reg"] <= tol["loss2"], rep
     assert opt.steps == 2
 
 

@@ -111,9 +111,37 @@ def test_resume_from_latest_pth(gpu_device, tmp_path):
     # an `optim` entry written by torch.optim.AdamW (the reference's) is refused with a clear message, the weights load
     torch.save({"steps": 3, "model": model.state_dict(), "optim": {"state": {}, "param_groups": [{}]}, "sched": sched.state_dict()},
                os.path.join(wd, "latest.pth"))
-    model3, opt3, _, steps3 = build_model(cfg, PoseModuleKD, dev)
+    model3, opt3, sched3, steps3 = build_model(cfg, PoseModuleKD, dev)
     assert steps3 == 3 and opt3.steps == 0
     assert torch.equal(model3.state_dict()["head.cls_logits.weight"], model.state_dict()["head.cls_logits.weight"])
+    # ... and the OneCycle schedule still continues from step 3 (the stale `sched` entry above is at step 4: it is
+    # replaced by a fresh schedule fast-forwarded to the checkpoint's step), only the Adam moments restart
+    ref_p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.AdamW([ref_p], lr=cfg["SOLVER"]["BASE_LR"], weight_decay=1e-4, eps=1e-8)
+    ref_sched = torch.optim.lr_scheduler.OneCycleLR(ref_opt, cfg["SOLVER"]["BASE_LR"], cfg["SOLVER"]["MAX_ITER"] + 100,
+                                                    pct_start=0.05, cycle_momentum=False, anneal_strategy="linear")
+    lrs = [ref_opt.param_groups[0]["lr"]]
+    for _ in range(5):
+        ref_opt.step(); ref_sched.step()
+        lrs.append(ref_opt.param_groups[0]["lr"])
+    assert sched3.last_epoch == 3 and opt3.param_groups[0]["lr"] == pytest.approx(lrs[3], rel=1e-9)
+    model3.train()
+    one_step(model3, opt3, sched3)
+    assert opt3.param_groups[0]["lr"] == pytest.approx(lrs[4], rel=1e-9)
+    # a latest.pth exactly as the reference writes it (train_kd.py:153-160): torch AdamW `optim`, torch OneCycleLR `sched`
+    ref_opt2 = torch.optim.AdamW([ref_p], lr=cfg["SOLVER"]["BASE_LR"], weight_decay=1e-4, eps=1e-8)
+    ref_sched2 = torch.optim.lr_scheduler.OneCycleLR(ref_opt2, cfg["SOLVER"]["BASE_LR"], cfg["SOLVER"]["MAX_ITER"] + 100,
+                                                     pct_start=0.05, cycle_momentum=False, anneal_strategy="linear")
+    for _ in range(3):
+        ref_opt2.step(); ref_sched2.step()
+    torch.save({"steps": 3, "model": model.state_dict(), "optim": ref_opt2.state_dict(), "sched": ref_sched2.state_dict()},
+               os.path.join(wd, "latest.pth"))
+    model4, opt4, sched4, steps4 = build_model(cfg, PoseModuleKD, dev)
+    assert steps4 == 3 and opt4.steps == 0 and sched4.last_epoch == 3
+    assert opt4.param_groups[0]["lr"] == pytest.approx(lrs[3], rel=1e-9)
+    model4.train()
+    one_step(model4, opt4, sched4)
+    assert opt4.param_groups[0]["lr"] == pytest.approx(lrs[4], rel=1e-9)
 
 
 def _encoded_pose_logits(targets, levels, B, noise, rng):

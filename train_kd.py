@@ -29,7 +29,8 @@ import torch  # noqa: E402
 from kd6d.arguments.argument_kd import get_args  # noqa: E402
 from kd6d._lib import lib  # noqa: E402
 from kd6d.kd_losses import PackedTargets  # noqa: E402
-from kd6d.libs.distributed import get_rank, init_exchange, shard_batch, synchronize  # noqa: E402
+from kd6d.libs.distributed import (get_rank, init_exchange, max_over_ranks, shard_batch, shutdown_exchange,  # noqa: E402
+                                   synchronize)
 from kd6d.libs.eval_libs import valid  # noqa: E402
 from kd6d.libs.train_libs import build_dataset, build_model, build_model_teacher, dataset_meshes  # noqa: E402
 from kd6d.models.model_kd import PoseModuleKD as PoseModule  # noqa: E402
@@ -104,6 +105,11 @@ if __name__ == "__main__":
     if device != "cuda":
         raise SystemExit("the kd6d step runs on MI355X only (--running_device cuda); the CPU restatement "
                          "lives in oracle/ and is test infrastructure")
+    if n_gpu > 1 and hasattr(os, "sched_setaffinity"):
+        # one host thread per rank issues ~1 ms of launches per step: keep it on its own slice of the cores
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(len(cpus) // n_gpu, 1)
+        os.sched_setaffinity(0, cpus[local_rank * per:(local_rank + 1) * per] or cpus)
     torch.cuda.set_device(local_rank)
     if cfg["RUNTIME"].get("TWO_LAUNCH_NORM_BWD"):
         from kd6d import ops
@@ -211,8 +217,13 @@ if __name__ == "__main__":
         if total_steps % 50 == 0 or total_steps % VAL_FREQ == 0:
             # in-kernel barriers of the one-launch BN / GN backward give up after a bounded spin instead of hanging
             # the GPU; a wait that gave up means wrong gradients, so training stops
-            n_to = lib.kd6d_barrier_timeouts()
+            # The decision is collective (MAX over ranks of the per-device counter): a rank that stopped alone would
+            # leave the others waiting in the next gradient all-reduce.
+            n_to = max_over_ranks(lib.kd6d_barrier_timeouts())
             if n_to != 0:
+                shutdown_exchange()
+                if cfg["RUNTIME"]["DISTRIBUTED"]:
+                    torch.distributed.destroy_process_group()
                 raise SystemExit("kd6d: %d in-kernel barrier waits timed out (gradients of a step are wrong); "
                                  "re-run with --two_launch_norm_bwd" % n_to)
         if get_rank() == 0 and total_steps % VAL_FREQ == 0:
@@ -227,3 +238,7 @@ if __name__ == "__main__":
         with open(os.path.join(wd, "info.txt"), "w") as f:
             f.write("finished at: %s\nworking_dir: %s\ncommands:%s" % (
                 time.strftime("%Y%m%d_%H%M%S"), wd, " ".join(sys.argv)))
+    if cfg["RUNTIME"]["DISTRIBUTED"]:
+        synchronize()
+        shutdown_exchange()                       # ncclCommDestroy of the kd6d communicator
+        torch.distributed.destroy_process_group()
