@@ -38,6 +38,73 @@ from torch import nn
 INF = 100000000
 
 # --------------------------------------------------------------------------------------
+# bf16-storage emulation (test infrastructure for the bf16 mode of the HIP path)
+# --------------------------------------------------------------------------------------
+# The HIP path in bf16 mode computes every convolution with bf16 operands and fp32 accumulation and STORES
+# activations / activation gradients as bf16; tensors feeding a normalisation, the logits, all parameters of the
+# epilogues (bias, BN / GN gain and shift), the losses, the weight gradients and the optimiser are fp32.
+# `with bf16_storage():` makes this restatement round at the same storage points -- fp32 arithmetic everywhere, values
+# passed through bf16 where the engine stores bf16 (straight-through in the other direction):
+#   _st(x)   value AND its gradient are stored bf16 (activations: conv inputs);
+#   _stg(x)  only the gradient is (fp32 pre-normalisation tensors and logits, whose gradients the reverse sweep stores);
+#   _w(w)    the bf16 shadow of a convolution weight (gradient reaches the fp32 master unrounded).
+# With it off (default) the three are identities and the module is the plain fp32 restatement pinned by the goldens.
+# Why it exists: the gradients of the student's first layers are so ill-conditioned at initialisation that rounding
+# only the INPUT IMAGE to bf16 moves them by 40-70 % (tests/bf16_sensitivity.py, profiles/r03_bf16_sensitivity.md),
+# so bf16-vs-fp32 deviations of those tensors measure the number format, not the kernels; against this emulation the
+# kernels are held to the summation-order level.
+_EMU = False
+
+
+class bf16_storage:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _EMU
+        self.old, _EMU = _EMU, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _EMU
+        _EMU = self.old
+        return False
+
+
+def _r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _Store(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fwd):
+        return _r(x) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g), None
+
+
+def _st(x):
+    return _Store.apply(x, True) if _EMU else x
+
+
+def _stg(x):
+    return _Store.apply(x, False) if (_EMU and x.requires_grad) else x
+
+
+def _w(w):
+    return w + (_r(w) - w).detach() if _EMU else w
+
+
+def _conv(m, x):
+    """nn.Conv2d `m` applied with the bf16 shadow of its weight under emulation (bias stays fp32)."""
+    if not _EMU:
+        return m(x)
+    return F.conv2d(x, _w(m.weight), m.bias, m.stride, m.padding)
+
+
+# --------------------------------------------------------------------------------------
 # networks
 # --------------------------------------------------------------------------------------
 
@@ -50,8 +117,10 @@ class ConvBlockRef(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
         self.bn = nn.BatchNorm2d(cout, eps=1e-5)
 
-    def forward(self, x):
-        return F.leaky_relu(self.bn(self.conv(x)), 0.1)
+    def forward(self, x, store=True):
+        # engine: raw conv output fp32 (its gradient `draw` is stored bf16), activation stored bf16
+        y = F.leaky_relu(self.bn(_stg(_conv(self.conv, x))), 0.1)
+        return _st(y) if store else y
 
 
 class DarkUnitRef(nn.Module):
@@ -61,7 +130,8 @@ class DarkUnitRef(nn.Module):
         self.conv2 = ConvBlockRef(cout // 2, cout, 3)
 
     def forward(self, x):
-        return self.conv2(self.conv1(x)) + x
+        # engine: the residual add is part of conv2's epilogue, one bf16 store behind it
+        return _st(self.conv2(self.conv1(x), store=False) + x)
 
 
 class DarkNet53Ref(nn.Module):
@@ -80,7 +150,7 @@ class DarkNet53Ref(nn.Module):
 
     def forward(self, x):
         f = self.features
-        o0 = f.init_block(x)
+        o0 = f.init_block(_st(x))
         o1 = f.stage1(o0); o2 = f.stage2(o1); o3 = f.stage3(o2); o4 = f.stage4(o3); o5 = f.stage5(o4)
         return [o1, o2, o3, o4, o5]
 
@@ -112,6 +182,7 @@ class DarkNetTinyRef(nn.Module):
 
     def forward(self, x):
         f = self.features
+        x = _st(x)                                      # the packed NHWC input image is bf16 in bf16 mode
         o1 = f.stage1(x); o2 = f.stage2(o1); o3 = f.stage3(o2)
         o4 = f.stage5(f.stage4(o3))
         return [o1, o2, o3, o4]
@@ -135,16 +206,16 @@ class FPNRef(nn.Module):
         self.top_blocks = _P6P7(in_channels[-1], out_channel)
 
     def forward(self, inputs):
-        inner = self.inner_convs[-1](inputs[-1])
-        outs = [self.out_convs[-1](inner)]
+        inner = _st(_conv(self.inner_convs[-1], inputs[-1]))
+        outs = [_st(_conv(self.out_convs[-1], inner))]
         for feat, ic, oc in zip(inputs[:-1][::-1], list(self.inner_convs)[:-1][::-1],
                                 list(self.out_convs)[:-1][::-1]):
             if ic is None:
                 continue
-            inner = ic(feat) + F.interpolate(inner, scale_factor=2, mode="nearest")
-            outs.insert(0, oc(inner))
-        p6 = self.top_blocks.p6(inputs[-1])            # use_p5=True: raw last backbone map
-        p7 = self.top_blocks.p7(F.relu(p6))
+            inner = _st(_st(_conv(ic, feat)) + F.interpolate(inner, scale_factor=2, mode="nearest"))
+            outs.insert(0, _st(_conv(oc, inner)))
+        p6 = _st(_conv(self.top_blocks.p6, inputs[-1]))            # use_p5=True: raw last backbone map
+        p7 = _st(_conv(self.top_blocks.p7, _st(F.relu(p6))))
         return outs + [p6, p7]
 
 
@@ -176,8 +247,18 @@ class PoseHeadRef(nn.Module):
     def forward(self, feats):
         cls, reg = [], []
         for l, f in enumerate(feats):
-            cls.append(self.cls_logits(self.cls_tower(f)))
-            reg.append(self.pose_pred(self.pose_tower(f)) * self.scales[l].scale)
+            if not _EMU:
+                cls.append(self.cls_logits(self.cls_tower(f)))
+                reg.append(self.pose_pred(self.pose_tower(f)) * self.scales[l].scale)
+                continue
+            outs = []
+            for tower, final in ((self.cls_tower, self.cls_logits), (self.pose_tower, self.pose_pred)):
+                x = f
+                for i in range(0, len(tower), 3):      # conv -> fp32 pre-GN tensor -> GroupNorm + ReLU -> bf16 store
+                    x = _st(tower[i + 2](tower[i + 1](_stg(_conv(tower[i], x)))))
+                outs.append(_stg(_conv(final, x)))     # fp32 logits; their gradients enter the sweep as bf16
+            cls.append(outs[0])
+            reg.append(outs[1] * self.scales[l].scale)
         return cls, reg
 
 
@@ -591,7 +672,10 @@ class KDStepRef:
 
     def __init__(self, student_arch="darknet_tiny_h", teacher_arch="darknet53", K=None, diameters=None,
                  kd_weight=5.0, base_lr=1e-3, max_iter=10000, n_gpu=1, w_cls=0.1, w_reg=1.0,
-                 kd=None, student_seed=1, teacher_seed=2, teacher_cls_bias=None):
+                 kd=None, student_seed=1, teacher_seed=2, teacher_cls_bias=None, emulate_bf16=False):
+        # emulate_bf16: both networks run under bf16_storage() (values rounded where the HIP path's bf16 mode stores
+        # bf16; see the top of this file) -- the yardstick for the bf16 parity tests, never a product path
+        self.emulate_bf16 = bool(emulate_bf16)
         self.student = PoseNetRef(student_arch)
         self.student.load_state_dict(seeded_state_dict(self.student, student_seed))
         self.teacher = None
@@ -612,7 +696,7 @@ class KDStepRef:
                                                          cycle_momentum=False, anneal_strategy="linear")
 
     def teacher_knowledge(self, images, targets):
-        with torch.no_grad():
+        with torch.no_grad(), bf16_storage(self.emulate_bf16):
             cls_t, reg_t = self.teacher(images)
         bt = torch.stack([t["bbox_trans"] for t in targets])
         return teacher_select(cls_t, reg_t, bt), (cls_t, reg_t)
@@ -627,7 +711,8 @@ class KDStepRef:
             teacher, t_logits = self.teacher_knowledge(images, targets)
             extras["teacher_logits"] = t_logits
             extras["teacher"] = teacher
-        cls_s, reg_s = self.student(images)
+        with bf16_storage(self.emulate_bf16):
+            cls_s, reg_s = self.student(images)
         shapes = [tuple(t.shape[-2:]) for t in cls_s]
         labels, gt_idx, aux = ssc_assign(targets, shapes, choose=choose)
         out = kd_pose_loss(cls_s, reg_s, targets, teacher, self.K, self.diameters, labels, gt_idx, aux, self.kd)

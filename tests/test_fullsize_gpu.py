@@ -121,19 +121,28 @@ def test_conv_layer_at_benchmark_shape(gpu_device, layer):
 # ---------------------------------------------------------------------------------------------------------
 # the whole step, replayed the way bench.py replays it
 # ---------------------------------------------------------------------------------------------------------
-def _grad_report(student, ref_grads, clip, gn_ref):
-    got = {k: p.grad.detach().float().cpu() for k, p in student.named_parameters() if p.grad is not None}
+def _grads(student):
+    return {k: p.grad.detach().float().cpu().clone() for k, p in student.named_parameters() if p.grad is not None}
+
+
+def _grad_report(student, ref_grads, clip, gn_ref, exclude=()):
+    """exclude: tensors left out of the per-tensor maxima (they still count in the weighted mean, the total and the
+    cosine); the caller passes the tensors whose gradient is not reproducible between two runs of the HIP path itself."""
+    got = _grads(student)
     dev_norm, dev_elem, num, den = {}, {}, 0.0, 0.0
     big = {}
     for k, g in ref_grads.items():
         r = g / clip
         rn = float(r.norm())
-        dev_norm[k] = abs(float(got[k].norm()) - rn) / max(rn, 1e-6 * gn_ref)
+        dn = abs(float(got[k].norm()) - rn) / max(rn, 1e-6 * gn_ref)
+        num += dn * rn ** 2
+        den += rn ** 2
+        if k in exclude:
+            continue
+        dev_norm[k] = dn
         dev_elem[k] = float((got[k] - r).norm()) / max(rn, 1e-6 * gn_ref)
         if g.numel() >= 1024:
             big[k] = dev_norm[k]
-        num += dev_norm[k] * rn ** 2
-        den += rn ** 2
     total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in got.values())))
     cos = float(sum((got[k].double() * (ref_grads[k] / clip).double()).sum() for k in ref_grads)) / (total * gn_ref)
     return dict(worst_norm=max(dev_norm.values()), worst_norm_name=max(dev_norm, key=dev_norm.get),
@@ -144,16 +153,26 @@ def _grad_report(student, ref_grads, clip, gn_ref):
 
 # precision -> (losses cls/reg rel, kd rel, grad norm rel, per-tensor norm worst, weighted mean, 1 - cosine,
 #               second-step losses rel, sign agreement of the first AdamW update)
+# fp32 is compared with the fp32 oracle.  bf16 is compared with the SAME oracle run under bf16-storage emulation
+# (oracle.kd_step_ref.bf16_storage: fp32 arithmetic, values rounded wherever the engine stores bf16).  Against the
+# plain fp32 oracle the per-tensor deviation of a bf16 step is dominated by the number format, not by the kernels: the
+# emulation itself sits 0.14-0.25 (norm) / 0.45-0.75 (element-wise) away from the fp32 oracle on the small BatchNorm
+# tensors of the backbone, and rounding ONLY the input image to bf16 already moves them by 0.4-0.7
+# (tests/bf16_sensitivity.py -> profiles/r03_bf16_sensitivity.md).  The deviations from the fp32 oracle are still
+# recorded (keys "vs_fp32_*" in gpurun_out/fullsize_parity.json) and bounded by TOL_BF16_VS_FP32.
 TOL = {
     "fp32": dict(loss=1e-3, kd=2e-3, gn=5e-3, worst=3e-2, worst1k=3e-2, wmean=1e-3, cos=1e-4, loss2=2e-2, sign=0.995),
-    # measured on MI355X (round 2, gpurun_out/fullsize_parity.json -> DESIGN.md section 6), config 2 / config 4:
-    # loss_cls 4.9e-4 / 6.4e-4, loss_reg 1.4e-3 / 1.2e-3, loss_kd 2.9e-3 / 2.1e-2, global grad norm 2.7e-4 / 3.1e-4,
-    # per-tensor norm worst 0.25 ... 0.61 / 0.14 ... 0.20 from run to run -- always an 8- or 16-element BatchNorm
-    # gain / bias of the first layers, whose gradient is a cancelling sum over 2^20 pixels of bf16-rounded
-    # incoming gradients (fp32 mode: 1 %); tensors of >= 1024 elements: see worst1k; weighted mean 8.5e-4 / 7.0e-4,
-    # 1 - cosine 4.8e-4 / 2.3e-4, second-step losses <= 1.5e-3 (kd 1.1e-2 / 2.1e-2), update-sign agreement 0.938 / 0.930
-    "bf16": dict(loss=3e-3, kd=4e-2, gn=1e-3, worst=1.3, worst1k=0.3, wmean=2e-3, cos=1e-3, loss2=8e-3, sign=0.90),
+    # measured on MI355X, round 3, config 2 / config 4 / S640 (gpurun_out/fullsize_parity.json -> profiles/
+    # r03_fullsize_parity.json): loss_cls 3e-5 / 1.2e-4 / 3e-6, loss_reg 1.2e-4 / 3.3e-4 / 2.3e-3, loss_kd 3.3e-3 / 8.5e-3 ... 2.4e-2 /
+    # 1.1e-3, global gradient norm 1.8e-4 / 1.4e-4 / 2.0e-4, per-tensor norm worst (reproducible tensors) 0.046 / 0.048 /
+    # 0.10, tensors >= 1024 elements 0.018 / 0.024 / 0.050, weighted mean 2.0e-4 / 1.6e-4 / 2.1e-4, 1 - cosine 9e-5 / 4e-5 /
+    # 1e-5, second-step losses <= 1e-3 (kd 2.1e-2), update-sign agreement 0.974 / 0.968 / 0.978
+    "bf16": dict(loss=4e-3, kd=4e-2, gn=1e-3, worst=0.2, worst1k=0.1, wmean=6e-4, cos=3e-4, loss2=3e-3, sign=0.955),
 }
+# two runs of the HIP path on the same inputs: a per-tensor gradient norm that moves by more than this is noise
+NOISY = 0.03
+# a bf16 step against the fp32 oracle (format error included): the round-2 bounds, for the record
+TOL_BF16_VS_FP32 = dict(loss=3e-3, kd=4e-2, gn=1e-3, worst=1.3, worst1k=0.3, wmean=2e-3, cos=1e-3)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -166,7 +185,23 @@ def test_benchmark_config_pipelined_graph_vs_oracle(gpu_device, precision, arch,
     _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full=False)
 
 
-_ORACLE_640 = {}
+_ORACLE = {}
+
+
+def _oracle_steps(arch, mixed, full, emulate, cpu_batches, choose, two_steps):
+    """Losses / gradient norm / per-parameter gradients of the oracle's first step (and the losses of its second),
+    once per process and configuration: the fp32 case and the bf16 case's record share the fp32 run."""
+    from kd6d.synthetic import INTERNAL_K, MESH_DIAMETERS
+    from oracle import kd_step_ref as O
+    key = (arch, mixed, full, emulate)
+    if key not in _ORACLE:
+        ref = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0,
+                          teacher_cls_bias=BIAS, emulate_bf16=emulate)
+        res1 = ref.step(*cpu_batches[0], choose=choose)
+        grads = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
+        res2 = ref.step(*cpu_batches[1], choose=choose) if two_steps else None
+        _ORACLE[key] = (res1, grads, res2)
+    return _ORACLE[key]
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -195,7 +230,6 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     opt = FusedClipAdamW(student, lr=1e-3, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 10100, pct_start=0.05, cycle_momentum=False,
                                                 anneal_strategy="linear")
-    ref = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0, teacher_cls_bias=BIAS)
     levels = [(60, 80), (30, 40), (15, 20), (8, 10)] if full else [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
     cells = sum(h * w for h, w in levels)
     counts = [h * w for h, w in levels]
@@ -214,6 +248,35 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     if mixed:
         assert len({int(t["class_ids"][0]) for t in cpu_batches[0][1]}) == 13
 
+    noisy = {}
+    if precision == "bf16":
+        # Reproducibility of the HIP path itself: the same first step from identical state in a second set of objects.
+        # fp32 atomics retire in a different order from run to run (1e-7 relative), a bf16 store turns that into
+        # occasional 2^-9 flips, and the small BatchNorm tensors of the first layers amplify those (a 1e-4 relative
+        # perturbation of the input image moves them by 10-30 % in the ORACLE, profiles/r03_bf16_sensitivity.md).  A
+        # tensor whose gradient norm differs by more than NOISY between two runs of the same binary on the same inputs
+        # cannot be held to a tighter bound against anything: it is reported, not bounded per tensor (it still counts
+        # in the global norm, the weighted mean, the cosine and the update-sign agreement).
+        twins = []
+        for _ in range(2):
+            t_ = build("darknet53", precision, 2, dev, BIAS).eval()
+            s_ = build(arch, precision, 1, dev).train()
+            s_._debug_keys = student._debug_keys
+            o_ = FusedClipAdamW(s_, lr=1e-3, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
+            g_ = GraphedKDStep(t_, s_, o_, (0.1, 1.0, 5.0), pipeline=True)
+            assert g_(*batches[0]) is None
+            g_(*batches[1])
+            torch.cuda.synchronize()
+            twins.append(_grads(s_))
+            del g_, o_, s_, t_
+        for k, a in twins[0].items():
+            na, nb = float(a.norm()), float(twins[1][k].norm())
+            d = abs(na - nb) / max(na, nb, 1e-30)
+            if d > NOISY:
+                noisy[k] = d
+        del twins
+        torch.cuda.empty_cache()
+
     gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=True)
     p0 = student.net.store.params.detach().cpu().clone()
     assert gs(*batches[0]) is None                          # priming call: teacher(0)
@@ -221,20 +284,34 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     torch.cuda.synchronize()
     got1 = {k: float(v) for k, v in ld.items()}
     gn1 = float(opt.grad_norm())
-    # oracle, step 1
-    if full and "res1" in _ORACLE_640:
-        res1, ref_grads = _ORACLE_640["res1"], _ORACLE_640["grads"]
-    else:
-        res1 = ref.step(*cpu_batches[0], choose=choose)
-        ref_grads = {k: p.grad.clone() for k, p in ref.student.named_parameters() if p.grad is not None}
-        if full:
-            _ORACLE_640.update(res1=res1, grads=ref_grads)
+    # oracle, step 1 (and 2): fp32 mode vs the fp32 oracle, bf16 mode vs its bf16-storage emulation (see TOL)
+    emulate = precision == "bf16"
+    res1, ref_grads, res2 = _oracle_steps(arch, mixed, full, emulate, cpu_batches, choose, two_steps=not full)
     clip = min(1.0, 1.0 / (res1["grad_norm"] + 1e-6))
-    rep = _grad_report(student, ref_grads, clip, res1["grad_norm"])
+    rep = _grad_report(student, ref_grads, clip, res1["grad_norm"], exclude=noisy)
+    rep["not_reproducible"] = noisy
+    # what is set aside this way must be a negligible part of the update: < 0.1 % of the squared gradient norm (measured:
+    # 10-20 of 150 tensors, nearly all BatchNorm gains / biases and narrow convolutions of the student's backbone, two-run
+    # deviation 3-21 %; FPN and head, where 99.9 % of the gradient's norm is, reproduce)
+    assert sum(float(ref_grads[k].norm()) ** 2 for k in noisy) <= 1e-3 * res1["grad_norm"] ** 2, noisy
+    if emulate and not full:
+        # for the record: the same bf16 step against the plain fp32 oracle (number-format error included)
+        f1, fgrads, _ = _oracle_steps(arch, mixed, full, False, cpu_batches, choose, two_steps=True)
+        fclip = min(1.0, 1.0 / (f1["grad_norm"] + 1e-6))
+        frep = _grad_report(student, fgrads, fclip, f1["grad_norm"])
+        rep.update({"vs_fp32_" + k: v for k, v in frep.items()})
+        rep.update({"vs_fp32_d_" + k: abs(got1[k] - f1[k]) / max(abs(f1[k]), 1e-6) for k in got1})
+        # ... and how far the emulation itself is from the fp32 oracle on the same tensors
+        erep = {}
+        for k, g in fgrads.items():
+            rn = float(g.norm())
+            if rn > 0:
+                erep[k] = abs(float(ref_grads[k].norm()) - rn) / rn
+        rep["emulation_vs_fp32_worst_norm"] = max(erep.values())
+        rep["emulation_vs_fp32_worst_norm_name"] = max(erep, key=erep.get)
     rep.update({"d_" + k: abs(got1[k] - res1[k]) / max(abs(res1[k]), 1e-6) for k in got1},
                d_grad_norm=abs(gn1 - res1["grad_norm"]) / res1["grad_norm"], losses=got1, oracle=res1)
     # first AdamW update: -lr * sign(g) where |g| is well above eps; compare the direction of travel element-wise
-    sd_ref = ref.student.state_dict()
     sd_got = student.state_dict()
     agree = count = 0
     for k, g in ref_grads.items():
@@ -252,7 +329,6 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     got2 = {k: float(v) for k, v in ld2.items()}
     assert all(v == v and abs(v) != float("inf") for v in got2.values()), got2
     if not full:
-        res2 = ref.step(*cpu_batches[1], choose=choose)
         rep.update({"d2_" + k: abs(got2[k] - res2[k]) / max(abs(res2[k]), 1e-6) for k in got2})
     rep["barrier_timeouts"] = int(ops.lib.kd6d_barrier_timeouts())
     _record("%s_%s" % (arch + ("_mixed13" if mixed else "") + ("_full640" if full else ""), precision), rep)
@@ -270,6 +346,12 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     if not full:
         assert rep["d2_loss_cls"] <= tol["loss2"] and rep["d2_loss_reg"] <= tol["loss2"], rep
     assert opt.steps == 2
+    if "vs_fp32_worst_norm" in rep:
+        t32 = TOL_BF16_VS_FP32
+        assert rep["vs_fp32_d_loss_cls"] <= t32["loss"] and rep["vs_fp32_d_loss_reg"] <= t32["loss"], rep
+        assert rep["vs_fp32_d_loss_kd"] <= t32["kd"] and rep["vs_fp32_total"] <= t32["gn"], rep
+        assert rep["vs_fp32_worst_norm"] <= t32["worst"] and rep["vs_fp32_worst_norm_1k"] <= t32["worst1k"], rep
+        assert rep["vs_fp32_wmean_norm"] <= t32["wmean"] and 1.0 - rep["vs_fp32_cosine"] <= t32["cos"], rep
 
 
 def _initial(student, p0, key):

@@ -19,6 +19,11 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# bf16 step vs the oracle's bf16-storage emulation, worst per-tensor gradient-norm deviation at B = 2 (by crop size);
+# measured on MI355X in round 3, bounds <= 2x the measurement (profiles/README.md)
+BF16_EMU_WORST = {128: 0.4, 256: 0.3}      # measured 0.12 / 0.18 (128x128), 0.04 ... 0.13 (256x256)
+
+
 def make_cfg(arch, precision):
     from kd6d.arguments.argument import custom_cfg
     with open(os.path.join(ROOT, "configs", "ape.yaml")) as f:
@@ -160,12 +165,58 @@ def test_step_against_reference_golden(gpu_device, name, precision):
         assert worst <= 2e-2 and wmean <= 1e-3, "per-parameter grad-norm deviation worst %.4f mean %.5f" % (worst, wmean)
         assert total == pytest.approx(gn_ref, rel=1e-2)
     else:
-        # measured (round 2): worst 0.24 / 0.23 at 128x128, 0.64 at 256x256 (a 64-element BatchNorm gain whose gradient
-        # is a cancelling sum over 131072 pixels of B = 2 images: positively homogeneous activations make the loss
-        # invariant to a common scale of the gains, what is left is rounding-sensitive; at B = 16 the same tensor is
-        # within 0.25, tests/test_fullsize_gpu.py); weighted mean <= 0.0038, global norm <= 0.0026
-        assert worst <= (1.3 if crop >= 256 else 0.5) and wmean <= 8e-3, (worst, wmean)
+        # bf16 vs the fp32 reference capture: the number format dominates the per-tensor figure (rounding only the
+        # input image to bf16 moves the small BatchNorm tensors of the backbone by tens of percent in the ORACLE,
+        # profiles/r03_bf16_sensitivity.md), so the golden bounds the aggregates ...
+        assert wmean <= 8e-3, (worst, wmean)
         assert total == pytest.approx(gn_ref, rel=6e-3)
+        # ... and the per-tensor norms are held against the oracle under bf16-storage emulation (same roundings, fp32
+        # arithmetic; the oracle itself is pinned by this golden in fp32), with the reference's SSC labels
+        from kd6d.synthetic import INTERNAL_K, MESH_DIAMETERS
+        from oracle import kd_step_ref as O
+        lab_img = torch.from_numpy(z["labels"].astype(np.int64)).reshape(B, -1)
+        cells = lab_img.shape[1]
+        counts = [h * w for h, w in levels_s]
+
+        def choose(vp, n, im, l, g):
+            off = sum(counts[:l])
+            picked = torch.nonzero(lab_img[im, off + vp] > 0).reshape(-1)
+            assert len(picked) == n, (len(picked), n)
+            return picked
+
+        emu = O.KDStepRef(arch, "darknet53", K=INTERNAL_K, diameters=MESH_DIAMETERS, kd_weight=5.0,
+                          teacher_cls_bias=[float(v) for v in z["teacher_cls_bias"]], emulate_bf16=True)
+        out, _ = emu.forward_backward(images.tensors, [t.as_dict() for t in targets], choose=choose)
+        eg = {k: p.grad for k, p in emu.student.named_parameters() if p.grad is not None}
+        egn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in eg.values())))
+        # tensors whose gradient the HIP path itself does not reproduce between two runs on the same inputs (float
+        # atomics retire in a different order, a bf16 store turns 1e-7 into occasional 2^-9 flips, the small BatchNorm
+        # tensors of the backbone amplify them) are reported, not bounded per tensor: see tests/test_fullsize_gpu.py
+        twins = []
+        for _ in range(2):
+            s_ = build(arch, precision, 1, dev).train()
+            s_._debug_keys = student._debug_keys
+            s_.zero_grad()
+            _, ld_ = s_(img, targets=tgt, pred_t=pred_t)
+            (ld_["loss_cls"] * 0.1 + ld_["loss_reg"] * 1.0 + ld_["loss_kd"] * 5.0).backward()
+            torch.cuda.synchronize()
+            twins.append({k: float(p.grad.float().norm()) for k, p in s_.named_parameters() if p.grad is not None})
+        noisy = {k: abs(a - twins[1][k]) / max(a, twins[1][k], 1e-30) for k, a in twins[0].items()}
+        noisy = {k: v for k, v in noisy.items() if v > 0.03}
+        # what is set aside must be a small part of the update: < 10 % of the squared gradient norm at B = 2 (measured
+        # 3.4 % / 3.2 % at 128x128, < 1 % at 256x256; at B = 16 the bound is 0.1 %, tests/test_fullsize_gpu.py)
+        assert sum(float(eg[k].norm()) ** 2 for k in noisy) <= 1e-1 * egn ** 2, noisy
+        dev_e = {k: abs(float(got[k].float().norm()) - float(eg[k].norm())) / max(float(eg[k].norm()), 1e-6 * egn)
+                 for k in eg if k not in noisy}
+        worst_e = max(dev_e.values())
+        print("[%s bf16] vs bf16-storage emulation: worst %.4f (%s), %d tensors not reproducible between two runs %s, losses %s" % (
+            name, worst_e, max(dev_e, key=dev_e.get), len(noisy), {k.replace("backbone.features.", ""): round(v, 3) for k, v in noisy.items()},
+            {k: float(v) for k, v in out.items() if torch.is_tensor(v) and v.numel() == 1}))
+        for k in ("loss_cls", "loss_reg"):
+            assert float(loss_dict[k]) == pytest.approx(float(out[k]), rel=1e-2)
+        assert float(loss_dict["loss_kd"]) == pytest.approx(float(out["loss_kd"]), rel=0.1)
+        assert worst_e <= BF16_EMU_WORST[crop], (worst_e, max(dev_e, key=dev_e.get))
+        assert total == pytest.approx(egn, rel=3e-3)
 
 
 def test_step_against_oracle_fp32_with_optimizer(gpu_device):
