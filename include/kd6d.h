@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 6
+#define KD6D_ABI_VERSION 7
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -94,6 +94,49 @@ int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x,
                     const float* ch_shift, int act, const void* residual,
                     const float* seg_scale, int out_f32, float* stats, int stats_groups,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Convolution (+ bias) with the normalisation and activation that follow it fused into its epilogue: one launch
+ * instead of conv -> statistics -> normalise, and the fp32 pre-normalisation tensor is not re-read (eval-mode callers
+ * do not even store it).  Replaces, of the reference: models/model.py:395-417,438-451 (tower Conv2d -> GroupNorm(32) ->
+ * ReLU) and backbone/common.py:316-324 in train mode (Conv2d -> BatchNorm2d(batch statistics) -> LeakyReLU(0.1)).
+ * The workgroups of the launch exchange their partial statistics through device-scope atomics and wait for the ones
+ * they need at an in-kernel barrier (GroupNorm: the tiles of the same (level, image); BatchNorm: the whole launch);
+ * every wait is bounded and counted by kd6d_barrier_timeouts().
+ *   kind      KD6D_NORM_GROUP | KD6D_NORM_BATCH;  groups: GroupNorm groups (4 or 8 channels per group)
+ *   y         (rows_out, cout) in `dtype`: act(norm(conv(x) + bias))
+ *   raw_out   optional (rows_out, cout) fp32: conv(x) + bias, what the backward pass of the normalisation reads
+ *   stats     pre-zeroed fp32: GROUP nseg*batch*groups*2 (the layout kd6d_gn_relu_bwd consumes);
+ *             BATCH KD6D_BN_FUSED_REPLICAS*2*cout (private layout)
+ *   counters  pre-zeroed 32-bit words: GROUP nseg*batch*KD6D_NORM_MAX_CTILES; BATCH KD6D_BARRIER_WORDS
+ *   BATCH only: momentum, running_mean / running_var (updated in place), save_mean / save_invstd (outputs for
+ *   kd6d_bn_train_bwd); all optional except the save pair.
+ * kd6d_conv2d_fwd_norm_fusable() tells whether this geometry takes the fused path (1) or not (0: the kernel the layer
+ * would run on has no fused epilogue, or -- BatchNorm -- its workgroups cannot all be resident at once on half of the
+ * device; call kd6d_conv2d_fwd + kd6d_bn_train_fwd / kd6d_gn_relu_fwd instead).  kd6d_conv2d_fwd_norm returns
+ * KD6D_ERR_UNSUPPORTED in that case.  Option "conv.fuse_norm" = 0 makes every geometry report 0. */
+#define KD6D_NORM_GROUP 1
+#define KD6D_NORM_BATCH 2
+#define KD6D_BN_FUSED_REPLICAS 8
+#define KD6D_NORM_MAX_CTILES 8
+typedef struct kd6d_conv_norm {
+  int32_t kind;
+  int32_t groups;
+  int32_t act;
+  float eps;
+  float momentum;
+  const float* gamma;
+  const float* beta;
+  void* y;
+  float* stats;
+  unsigned int* counters;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+} kd6d_conv_norm;
+int kd6d_conv2d_fwd_norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups);
+int kd6d_conv2d_fwd_norm(const kd6d_conv_geom* g, int dtype, const void* x, const void* w, void* raw_out,
+                         const float* bias, const kd6d_conv_norm* norm, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  wt is the dgrad packing wt[cin][ky][kx][cout]
  * produced by kd6d_pack_dgrad_weights.  accumulate != 0 adds into dx. */

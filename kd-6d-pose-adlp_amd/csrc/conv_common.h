@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "kd6d_barrier.h"
 #include "kd6d_common.h"
 
 namespace kd6d_detail {
@@ -57,6 +58,21 @@ struct ConvParams {
   float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
   int nk_split;        // k-steps per split
   int stats_cpg_shift; // log2(channels per group): 2 or 3
+  // ---- normalisation + activation fused behind the convolution (conv_epilogue_norm; kd6d_conv2d_fwd_norm) ----
+  void* norm_dst;              // non-null: once the statistics are complete across workgroups, act(norm(v)) goes here (T)
+  const float* norm_gamma;
+  const float* norm_beta;
+  unsigned int* norm_ctr;      // pre-zeroed words: BatchNorm KD6D_BARRIER_WORDS; GroupNorm one per (level, image, channel tile)
+  unsigned int* norm_timeouts; // the library's counter of barrier waits that gave up
+  float norm_eps;
+  int norm_act;
+  int stats_replicas;          // BatchNorm, fused: rows {sum[N], sumsq[N]} of `stats` (workgroup b adds to row b % replicas)
+  int linear_tiles;            // 1: workgroup id == tile id (no XCD remap): tiles that wait for each other are dispatched together
+  float bn_inv_rows, bn_momentum, bn_unbias;
+  float* bn_save_mean;
+  float* bn_save_invstd;
+  float* bn_running_mean;
+  float* bn_running_var;
 };
 
 template <typename T> struct Frag;
@@ -107,6 +123,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ int tile_of_workgroup(const ConvParams& p, int bid, int nwg) {
+  return p.linear_tiles ? bid : xcd_remap(bid, nwg);
+}
+
+// (level, image) key of GEMM row m: level * batch + image.  Monotone in m (levels are packed level-major, image-major).
+__device__ __forceinline__ int stats_key(const ConvParams& p, int m) {
+  int mb = 0, hw = 1, sg = 0;
+  float inv = 1.f;
+#pragma unroll
+  for (int s = 0; s < kMaxSeg; ++s)
+    if (s < p.nseg && m >= p.seg[s].m_begin) {
+      mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg[s].inv_hw;
+    }
+  return sg * p.batch + fast_div(m - mb, hw, inv);
 }
 
 // Decode GEMM row m -> (level fields) without dynamic indexing of the kernarg table.
@@ -198,9 +230,16 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
       }
     }
     __syncthreads();
+    // fused normalisation: replica rows (hundreds of workgroups adding into one address retire one after the other,
+    // ~25 ns each) and RETURNING atomics (visible before this workgroup arrives at the barrier, kd6d_barrier.h)
+    const int rep = p.norm_dst && p.stats_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.stats_replicas) : 0;
     for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
       const int which = i / BC, nl = i - which * BC;
-      if (n0 + nl < p.N) atomicAdd(p.stats + (size_t)which * p.N + n0 + nl, red[i]);
+      if (n0 + nl < p.N) {
+        float* o = p.stats + (size_t)(rep * 2 + which) * p.N + n0 + nl;
+        if (p.norm_dst) atomic_add_performed(o, red[i]);
+        else atomicAdd(o, red[i]);
+      }
     }
     return;
   }
@@ -208,21 +247,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
   const int G = p.stats_groups;
   const int cs = p.stats_cpg_shift;        // 4 or 8 channels per group: a lane's 4 aligned channels share one
   const int GT = BC >> cs;                 // groups touched by this channel tile
-  auto key_of = [&](int m) {
-    int mb = 0, hw = 1, sg = 0;
-    float inv = 1.f;
-#pragma unroll
-    for (int s = 0; s < kMaxSeg; ++s)
-      if (s < p.nseg && m >= p.seg[s].m_begin) {
-        mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg[s].inv_hw;
-      }
-    // (m - mb) / hw without an integer division (operands < 2^24): float estimate, then one correction step
-    const int xx = m - mb;
-    int b = (int)((float)xx * inv);
-    b += ((b + 1) * hw <= xx) ? 1 : 0;
-    b -= (b * hw > xx) ? 1 : 0;
-    return sg * p.batch + b;               // monotone in m: levels are packed level-major, image-major
-  };
+  auto key_of = [&](int m) { return stats_key(p, m); };
   const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
   const int key_lo = key_of(m0);
   const int nkeys = key_of(m_last) - key_lo + 1;
@@ -271,7 +296,11 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
   for (int i = threadIdx.x; i < tab; i += blockDim.x) {
     const int k = i >> gts, rem = i & (GT * 2 - 1);
     const int gl = rem >> 1;
-    if (g_first + gl < G) atomicAdd(p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1), red[i]);
+    if (g_first + gl < G) {
+      float* o = p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1);
+      if (p.norm_dst) atomic_add_performed(o, red[i]);
+      else atomicAdd(o, red[i]);
+    }
   }
 }
 
@@ -427,7 +456,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
           }
         }
         if (p.stats) acc[c][q] = f32x4_t{v[0], v[1], v[2], v[3]};
-        if (p.out_f32) {
+        if (!p.dst) {
+          // statistics only: the caller consumes the values from the accumulators (conv_epilogue_norm)
+        } else if (p.out_f32) {
           *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
               f32x4_t{v[0], v[1], v[2], v[3]};
         } else if (sizeof(T) == 4) {
@@ -462,6 +493,200 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
   if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
 }
 
+// ---------------------------------------------------------------------------
+// Normalisation + activation fused behind the convolution (replaces a separate bn_apply / gn_relu_fwd launch and the
+// re-read of the fp32 pre-normalisation tensor; models/model.py:395-417 GroupNorm(32) + ReLU of the towers,
+// backbone/common.py:316-324 train-mode BatchNorm + LeakyReLU).  Phase 1 is conv_epilogue: the pre-normalisation
+// values (optionally stored as fp32 for the backward pass) and their statistics, added across workgroups with
+// returning device-scope atomics.  Then the workgroup waits until the statistics it needs are complete --
+//   BatchNorm: every workgroup of the launch (grid barrier);
+//   GroupNorm: the pixel tiles that share one of this tile's (level, image) keys, per channel tile: one counter per
+//              (key, channel tile), every tile arrives at each key it touches (kd6d_barrier.h: window barrier);
+// -- reads the totals back with device-scope loads and finishes act(norm(v)) from the accumulators it still holds.
+// ---------------------------------------------------------------------------
+template <typename T, int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void conv_epilogue_norm(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
+                                                   int m0, int n0, int wp, int wc, int lane, float* red, int bid,
+                                                   int nwg, int tile_c) {
+  constexpr int PI = BP / WP / 16;
+  constexpr int CI = BC / WC / 16;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (p.stats_groups == 0) {
+    // ---- BatchNorm (train): statistics over all rows of the launch ----
+    grid_barrier(p.norm_ctr, (unsigned)bid, (unsigned)nwg, p.norm_timeouts);
+    const int R = p.stats_replicas > 1 ? p.stats_replicas : 1;
+    for (int i = tid; i < 2 * BC; i += nthr) {
+      const int which = i / BC, nl = i - which * BC;
+      float t = 0.f;
+      if (n0 + nl < p.N)
+        for (int r = 0; r < R; ++r) t += load_device_scope(p.stats + (size_t)(r * 2 + which) * p.N + n0 + nl);
+      red[i] = t;
+    }
+    __syncthreads();
+    if (m0 == 0) {           // one workgroup per channel tile publishes what the backward pass and eval mode need
+      for (int nl = tid; nl < BC; nl += nthr) {
+        const int n = n0 + nl;
+        if (n >= p.N) continue;
+        const float mean = red[nl] * p.bn_inv_rows;
+        const float var = fmaxf(red[BC + nl] * p.bn_inv_rows - mean * mean, 0.f);
+        if (p.bn_save_mean) p.bn_save_mean[n] = mean;
+        if (p.bn_save_invstd) p.bn_save_invstd[n] = rsqrtf(var + p.norm_eps);
+        if (p.bn_running_mean) p.bn_running_mean[n] = (1.f - p.bn_momentum) * p.bn_running_mean[n] + p.bn_momentum * mean;
+        if (p.bn_running_var) p.bn_running_var[n] = (1.f - p.bn_momentum) * p.bn_running_var[n] + p.bn_momentum * var * p.bn_unbias;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+      const int n = n0 + nl;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float mean = red[nl + r] * p.bn_inv_rows;
+        const float var = fmaxf(red[BC + nl + r] * p.bn_inv_rows - mean * mean, 0.f);
+        const float sc = p.norm_gamma[n + r] * rsqrtf(var + p.norm_eps);
+        const float sh = __builtin_fmaf(-mean, sc, p.norm_beta[n + r]);
+#pragma unroll
+        for (int q = 0; q < PI; ++q) {
+          float t = __builtin_fmaf(acc[c][q][r], sc, sh);
+          if (p.norm_act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+          else if (p.norm_act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+          acc[c][q][r] = t;
+        }
+      }
+    }
+  } else {
+    // ---- GroupNorm: statistics per (level, image, group) ----
+    const int G = p.stats_groups, cs = p.stats_cpg_shift;
+    const int GT = BC >> cs;
+    const int gts = 31 - __clz(GT);
+    const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
+    const int key_lo = stats_key(p, m0);
+    const int nkeys = stats_key(p, m_last) - key_lo + 1;
+    // rows [ks, ke] of key k in GEMM-row space and its pixel count
+    auto key_rows = [&](int key, int& ks, int& hw) {
+      int sg = 0;
+#pragma unroll
+      for (int s = 1; s < kMaxSeg; ++s)
+        if (s < p.nseg && key >= s * p.batch) sg = s;
+      int mb = 0;
+      hw = 1;
+#pragma unroll
+      for (int s = 0; s < kMaxSeg; ++s)
+        if (s == sg) { mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; }
+      ks = mb + (key - sg * p.batch) * hw;
+    };
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();            // every thread's statistics are performed (conv_epilogue_stats) before the arrivals
+    for (int k = tid; k < nkeys; k += nthr) {
+      int ks, hw;
+      key_rows(key_lo + k, ks, hw);
+      const unsigned need = (unsigned)((ks + hw - 1) / BP - ks / BP + 1);
+      arrive_and_wait(p.norm_ctr + (size_t)(key_lo + k) * p.n_ctiles + tile_c, need, p.norm_timeouts);
+    }
+    __syncthreads();
+    const int tab = nkeys << gts;
+    const int g_first = n0 >> cs;
+    for (int i = tid; i < tab; i += nthr) {
+      const int k = i >> gts, gl = i & (GT - 1);
+      float mu = 0.f, rs = 0.f;
+      if (g_first + gl < G) {
+        int ks, hw;
+        key_rows(key_lo + k, ks, hw);
+        const float* st = p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2;
+        const float s1 = load_device_scope(st), s2 = load_device_scope(st + 1);
+        const float inv_n = 1.f / ((float)hw * (float)(1 << cs));
+        mu = s1 * inv_n;
+        rs = rsqrtf(fmaxf(s2 * inv_n - mu * mu, 0.f) + p.norm_eps);
+      }
+      red[2 * i] = mu;
+      red[2 * i + 1] = rs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PI; ++q) {
+      const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+      const int key = m < p.M ? stats_key(p, m) - key_lo : 0;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+        const int n = n0 + nl;
+        if (n >= p.N) continue;
+        const float* mr = red + (((key << gts) + (nl >> cs)) << 1);
+        const float mu = mr[0], rs = mr[1];
+        const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(p.norm_gamma + n);
+        const f32x4_t be = *reinterpret_cast<const f32x4_t*>(p.norm_beta + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = (acc[c][q][r] - mu) * rs * ga[r] + be[r];
+          if (p.norm_act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+          else if (p.norm_act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+          acc[c][q][r] = t;
+        }
+      }
+    }
+  }
+  // ---- store the activation: 16 B per lane (fp32: 4 channels; bf16: 8 channels through the lane-pair swap of
+  // conv_epilogue, 4 channels = 8 B where a wave holds an odd number of channel tiles) ----
+  const bool odd = fq & 1;
+  const int partner = (lane ^ 16) << 2;
+#pragma unroll
+  for (int q = 0; q < PI; ++q) {
+    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
+    const bool row_ok = m < p.M;
+    int drow = m;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s)
+      if (s < p.nseg && m >= p.seg[s].m_begin) drow = p.seg[s].dst_row0 + (m - p.seg[s].m_begin);
+    if constexpr (sizeof(T) == 2 && (CI % 2 == 0)) {
+      if ((p.N & 7) == 0) {
+#pragma unroll
+        for (int cp = 0; cp < CI / 2; ++cp) {
+          const f32x4_t va0 = acc[2 * cp][q], va1 = acc[2 * cp + 1][q];
+          const f32x4_t send = odd ? va0 : va1;
+          f32x4_t got;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            got[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(send[r])));
+          const f32x4_t lo = odd ? got : va0, hi = odd ? va1 : got;
+          const int n = n0 + wc * (BC / WC) + (2 * cp + (odd ? 1 : 0)) * 16 + (fq & ~1) * 4;
+          if (!row_ok || n >= p.N) continue;
+          u32x4_t pk;
+          pk.x = pack_bf16x2(lo[0], lo[1]); pk.y = pack_bf16x2(lo[2], lo[3]);
+          pk.z = pack_bf16x2(hi[0], hi[1]); pk.w = pack_bf16x2(hi[2], hi[3]);
+          *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(p.norm_dst) + (size_t)drow * (size_t)p.N + (size_t)n) = pk;
+        }
+        continue;
+      }
+    }
+    if (!row_ok) continue;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int n = n0 + wc * (BC / WC) + c * 16 + fq * 4;
+      if (n >= p.N) continue;
+      const size_t o = (size_t)drow * (size_t)p.N + (size_t)n;
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.norm_dst) + o) = acc[c][q];
+      } else {
+        u32x2_t pk;
+        pk.x = pack_bf16x2(acc[c][q][0], acc[c][q][1]);
+        pk.y = pack_bf16x2(acc[c][q][2], acc[c][q][3]);
+        *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.norm_dst) + o) = pk;
+      }
+    }
+  }
+}
+
+// What the kernels call: conv_epilogue, then the fused normalisation when the launch carries one.
+template <typename T, int BP, int BC, int WP, int WC, bool WIDE = true>
+__device__ __forceinline__ void conv_epilogue_full(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
+                                                   int m0, int n0, int wp, int wc, int lane, float* smem_f32, int bid,
+                                                   int nwg, int tile_c) {
+  conv_epilogue<T, BP, BC, WP, WC, WIDE>(p, acc, m0, n0, wp, wc, lane, smem_f32);
+  if (p.norm_dst) conv_epilogue_norm<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32, bid, nwg, tile_c);
+}
 
 static __device__ const uint4 kd6d_zero_page[4] = {};
 
@@ -545,6 +770,21 @@ static inline void set_tile_order(ConvParams& q, int ptiles, int BP, int BC) {
 static inline int cached_cu_count() {       // one device per process
   static const int n = []() { const int c = kd6d_device_cu_count(); return c > 0 ? c : 256; }();
   return n;
+}
+
+// Dry run of the forward dispatch (kd6d_conv2d_fwd_norm_fusable): while g_launch_plan is set, the launch functions
+// record what they would launch instead of launching it.
+struct LaunchPlan {
+  int grid = 0, threads = 0;
+  size_t lds = 0;
+  bool fused_epilogue = false;     // the kernel ends in conv_epilogue_full
+};
+extern thread_local LaunchPlan* g_launch_plan;
+static inline bool plan_only(int grid, int threads, size_t lds, bool fused_epilogue) {
+  if (!g_launch_plan) return false;
+  g_launch_plan->grid = grid; g_launch_plan->threads = threads; g_launch_plan->lds = lds;
+  g_launch_plan->fused_epilogue = fused_epilogue;
+  return true;
 }
 
 // conv_halo.hip: the 3x3 / stride 1 halo-patch kernel takes the layer (returns false: not its shape / too few tiles)

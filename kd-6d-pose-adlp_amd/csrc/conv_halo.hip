@@ -54,7 +54,7 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = xcd_remap(bid, nwg);
+  const int wg = tile_of_workgroup(p, bid, nwg);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
 #pragma unroll
     for (int q = 0; q < PI; ++q) mma(ga[c], gb[q], acc[c][q]);
   __syncthreads();             // the epilogue reuses the LDS the last k-step may still be reading
-  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+  conv_epilogue_full<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), bid, nwg, tile_c);
 }
 
 // second launch bound = waves per SIMD the register budget has to leave room for: the single-buffer variants are
@@ -311,6 +311,7 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
   r.halo = halo; r.total_rows = total_rows; r.tiles = ptiles * r.q.n_ctiles; r.st = st;
   r.single = &halo_issue_single<BP, BC, WP, WC, MODE, HMAX, PDB>;
   r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE, HMAX, PDB>;
+  if (plan_only(r.tiles, WP * WC * 64, halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>(), true)) return;
   if (g_pair.active && g_pair.count < 2) { g_pair.rec[g_pair.count++] = r; return; }
   r.single(r);
 }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wg = tile_of_workgroup(p, blockIdx.x, gridDim.x);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+  conv_epilogue_full<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), blockIdx.x,
+                                        gridDim.x, tile_c);
 }
 
 // ---------------------------------------------------------------------------
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wg = tile_of_workgroup(p, blockIdx.x, gridDim.x);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
     }
     return;
   }
-  conv_epilogue<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem));
+  conv_epilogue_full<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), blockIdx.x,
+                                        gridDim.x, tile_c);
 }
 
 // out = epilogue(sum over splits of the fp32 partial tiles), 4 channels per thread.
@@ -1167,6 +1169,7 @@ void launch_igemm(const ConvParams& p, hipStream_t st) {
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)(BP + BC) * 128 * 2;
+  if (plan_only(ptiles * q.n_ctiles, 256, lds, true)) return;
   auto kern = conv_igemm_kernel<T, BP, BC, WP, WC, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1184,6 +1187,7 @@ void launch_glds(const ConvParams& p, hipStream_t st) {
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)(BP + BC) * 128 * NSTAGE;
+  if (plan_only(ptiles * q.n_ctiles, 256, lds, true)) return;
   auto kern = conv_igemm_glds_kernel<BP, BC, WP, WC, MODE, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1227,6 +1231,7 @@ bool dispatch_smallc(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t s
   if (force == 0) return false;
   if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C != 8 && p.C != 16 && p.C != 32) || (p.N & 3)) return false;
   if (p.stats && p.stats_groups > 0) return false;      // the group-statistics table wants the big staging buffers
+  if (p.norm_dst) return false;                         // no fused-normalisation epilogue in this kernel
   // one burst per workgroup, no pipeline: pays once >= 2 workgroups per CU overlap each other (measured: the
   // 64x64-pixel layers and below are faster on the pipelined kernels)
   if (force < 0 && p.M < (1 << 17)) return false;
@@ -1304,6 +1309,9 @@ template <int MODE>
 bool dispatch_glds(const ConvParams& p, hipStream_t st) {
   const int force = (int)kd6d_opt(KD6D_OPT_CONV_TILE);
   if (force == 0 || p.N <= 32) return false;
+  // fused BatchNorm (grid barrier: every workgroup of the launch resident at once, kd6d_barrier.h): the register-staged
+  // kernel's 32-48 KB tiles instead of this one's 64-KB rings
+  if (p.norm_dst && p.stats_groups == 0 && force < 0) return false;
   const int N = p.N, M = p.M;
   auto nblocks = [&](int bp, int bc) { return ((M + bp - 1) / bp) * ((N + bc - 1) / bc); };
   // measured (tools/bench_conv.py): with enough workgroups the register-staged kernel is as fast or faster
@@ -1488,34 +1496,13 @@ void dispatch_wgrad(const WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
-                               void* y, const float* ch_scale, const float* ch_shift, int act,
-                               const void* residual, const float* seg_scale, int out_f32,
-                               float* stats, int stats_groups, void* workspace, int64_t workspace_bytes,
-                               void* stream) {
-  int rc = check_geom(g, dtype, "kd6d_conv2d_fwd");
-  if (rc) return rc;
-  KD6D_CHECK_ARG(x && w && y, "kd6d_conv2d_fwd: null tensor pointer");
-  KD6D_CHECK_ARG(act >= 0 && act <= 2, "kd6d_conv2d_fwd: bad act %d", act);
-  ConvParams p;
-  memset(&p, 0, sizeof(p));
-  p.nseg = g->nseg; p.batch = g->batch; p.C = g->cin; p.N = g->cout;
-  p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad;
-  p.K = g->ksize * g->ksize * g->cin;
-  KD6D_CHECK_ARG(fill_segs(g, false, p.seg, &p.M), "kd6d_conv2d_fwd: grid too large");
-  p.src = x; p.wgt = w; p.dst = y;
-  p.ch_scale = ch_scale; p.ch_shift = ch_shift; p.residual = residual; p.seg_scale = seg_scale;
-  p.act = act; p.out_f32 = out_f32 ? 1 : 0;
-  if (stats) {
-    KD6D_CHECK_ARG(g->cout % 4 == 0 && stats_groups >= 0, "kd6d_conv2d_fwd: fused statistics need cout %% 4 == 0");
-    KD6D_CHECK_ARG(stats_groups == 0 || (g->cout % stats_groups == 0 && (g->cout / stats_groups) % 4 == 0 &&
-                                         g->cout / stats_groups <= 8),
-                   "kd6d_conv2d_fwd: fused group statistics need 4 or 8 channels per group (cout=%d, groups=%d)",
-                   g->cout, stats_groups);
-    p.stats = stats; p.stats_groups = stats_groups;
-    if (stats_groups > 0) p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
-  }
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+thread_local kd6d_detail::LaunchPlan* kd6d_detail::g_launch_plan = nullptr;
+
+namespace {
+
+// forward dispatch: the per-layer kernel choice
+void dispatch_fwd(const ConvParams& p, const kd6d_conv_geom* g, int dtype, void* workspace, int64_t workspace_bytes,
+                  hipStream_t st) {
   if (dtype == KD6D_BF16) {
     if (!dispatch_smallc<MODE_FWD>(p, g, st) && !dispatch_halo_fwd(p, g, st) &&
         !dispatch_splitk<MODE_FWD>(p, reinterpret_cast<float*>(workspace), (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), st) &&
@@ -1524,7 +1511,130 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
   } else {
     dispatch_igemm<float, MODE_FWD>(p, st);
   }
+}
+
+int fwd_params(const kd6d_conv_geom* g, int dtype, const char* who, ConvParams& p) {
+  int rc = check_geom(g, dtype, who);
+  if (rc) return rc;
+  memset(&p, 0, sizeof(p));
+  p.nseg = g->nseg; p.batch = g->batch; p.C = g->cin; p.N = g->cout;
+  p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad;
+  p.K = g->ksize * g->ksize * g->cin;
+  KD6D_CHECK_ARG(fill_segs(g, false, p.seg, &p.M), "%s: grid too large", who);
+  return KD6D_OK;
+}
+
+int set_stats(const kd6d_conv_geom* g, ConvParams& p, float* stats, int stats_groups, const char* who) {
+  KD6D_CHECK_ARG(g->cout % 4 == 0 && stats_groups >= 0, "%s: fused statistics need cout %% 4 == 0", who);
+  KD6D_CHECK_ARG(stats_groups == 0 || (g->cout % stats_groups == 0 && (g->cout / stats_groups) % 4 == 0 &&
+                                       g->cout / stats_groups <= 8),
+                 "%s: fused group statistics need 4 or 8 channels per group (cout=%d, groups=%d)", who, g->cout,
+                 stats_groups);
+  p.stats = stats; p.stats_groups = stats_groups;
+  if (stats_groups > 0) p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
+  return KD6D_OK;
+}
+
+// Would kd6d_conv2d_fwd_norm take the fused path?  Dry run of the dispatch with the fields that steer it set the way
+// the real call sets them, then the residency rule of kd6d_barrier.h.
+bool norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups, ConvParams& p, LaunchPlan& plan) {
+  if (kd6d_opt(KD6D_OPT_CONV_FUSE_NORM) == 0) return false;
+  if (fwd_params(g, dtype, "kd6d_conv2d_fwd_norm", p) != KD6D_OK) return false;
+  static float dummy;
+  if (set_stats(g, p, &dummy, kind == KD6D_NORM_GROUP ? groups : 0, "kd6d_conv2d_fwd_norm") != KD6D_OK) return false;
+  if (kind == KD6D_NORM_GROUP && groups <= 0) return false;
+  p.norm_dst = &dummy;
+  p.out_f32 = 1;
+  g_launch_plan = &plan;
+  dispatch_fwd(p, g, dtype, nullptr, 0, nullptr);
+  g_launch_plan = nullptr;
+  if (!plan.fused_epilogue || plan.grid <= 0) return false;
+  const int ncu = cached_cu_count();
+  const size_t lds = plan.lds > 0 ? plan.lds : 1;
+  const int waves = plan.threads / 64;
+  if (kind == KD6D_NORM_BATCH) {
+    // grid barrier: every workgroup of the launch pinned until the last one has arrived.  Admit only launches that fit
+    // in HALF of the device's LDS and wave slots (the other half is what window-barrier launches on other streams and
+    // fragmentation may hold), at no more than two workgroups per CU
+    if ((size_t)plan.grid * lds > (size_t)ncu * (160u << 10) / 2) return false;
+    if (plan.grid * waves > ncu * 32 / 2) return false;
+    if (plan.grid > 2 * ncu) return false;
+  } else {
+    // window barrier: with workgroup id == tile id a tile waits for the pixel tiles of its own (level, image) keys only
+    int hw_max = 1;
+    for (int s = 0; s < g->nseg; ++s) hw_max = hw_max > g->seg[s].out_h * g->seg[s].out_w ? hw_max : g->seg[s].out_h * g->seg[s].out_w;
+    const int n_ctiles = (g->cout + 15) / 16;       // upper bound of the channel tiles
+    if (n_ctiles > 16 * KD6D_NORM_MAX_CTILES) return false;
+    (void)hw_max;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
+                               void* y, const float* ch_scale, const float* ch_shift, int act,
+                               const void* residual, const float* seg_scale, int out_f32,
+                               float* stats, int stats_groups, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  ConvParams p;
+  int rc = fwd_params(g, dtype, "kd6d_conv2d_fwd", p);
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && w && y, "kd6d_conv2d_fwd: null tensor pointer");
+  KD6D_CHECK_ARG(act >= 0 && act <= 2, "kd6d_conv2d_fwd: bad act %d", act);
+  p.src = x; p.wgt = w; p.dst = y;
+  p.ch_scale = ch_scale; p.ch_shift = ch_shift; p.residual = residual; p.seg_scale = seg_scale;
+  p.act = act; p.out_f32 = out_f32 ? 1 : 0;
+  if (stats) {
+    rc = set_stats(g, p, stats, stats_groups, "kd6d_conv2d_fwd");
+    if (rc) return rc;
+  }
+  dispatch_fwd(p, g, dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   KD6D_CHECK_LAUNCH("kd6d_conv2d_fwd");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_conv2d_fwd_norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups) {
+  if (!g || (kind != KD6D_NORM_GROUP && kind != KD6D_NORM_BATCH)) return 0;
+  ConvParams p;
+  LaunchPlan plan;
+  return norm_fusable(g, dtype, kind, groups, p, plan) ? 1 : 0;
+}
+
+extern "C" int kd6d_conv2d_fwd_norm(const kd6d_conv_geom* g, int dtype, const void* x, const void* w, void* raw_out,
+                                    const float* bias, const kd6d_conv_norm* norm, void* stream) {
+  KD6D_CHECK_ARG(g && x && w && norm && norm->y && norm->gamma && norm->beta && norm->stats && norm->counters,
+                 "kd6d_conv2d_fwd_norm: null pointer");
+  KD6D_CHECK_ARG(norm->kind == KD6D_NORM_GROUP || norm->kind == KD6D_NORM_BATCH, "kd6d_conv2d_fwd_norm: bad kind %d", norm->kind);
+  KD6D_CHECK_ARG(norm->act >= 0 && norm->act <= 2, "kd6d_conv2d_fwd_norm: bad act %d", norm->act);
+  KD6D_CHECK_ARG(norm->kind != KD6D_NORM_BATCH || (norm->save_mean && norm->save_invstd),
+                 "kd6d_conv2d_fwd_norm: BatchNorm needs save_mean / save_invstd");
+  ConvParams p;
+  LaunchPlan plan;
+  if (!norm_fusable(g, dtype, norm->kind, norm->groups, p, plan)) {
+    kd6d_set_error("kd6d_conv2d_fwd_norm: this geometry does not take the fused path (kd6d_conv2d_fwd_norm_fusable)");
+    return KD6D_ERR_UNSUPPORTED;
+  }
+  unsigned int* timeouts = barrier_timeouts_device_ptr();
+  KD6D_CHECK_ARG(timeouts != nullptr, "kd6d_conv2d_fwd_norm: no barrier-timeout counter");
+  p.src = x; p.wgt = w; p.dst = raw_out;
+  p.ch_shift = bias; p.act = KD6D_ACT_NONE; p.out_f32 = 1;
+  p.stats = norm->stats;
+  p.norm_dst = norm->y; p.norm_gamma = norm->gamma; p.norm_beta = norm->beta;
+  p.norm_ctr = norm->counters; p.norm_timeouts = timeouts;
+  p.norm_eps = norm->eps; p.norm_act = norm->act;
+  if (norm->kind == KD6D_NORM_BATCH) {
+    p.stats_replicas = KD6D_BN_FUSED_REPLICAS;
+    p.bn_inv_rows = 1.0f / (float)p.M;
+    p.bn_momentum = norm->momentum;
+    p.bn_unbias = p.M > 1 ? (float)p.M / (float)(p.M - 1) : 1.0f;
+    p.bn_save_mean = norm->save_mean; p.bn_save_invstd = norm->save_invstd;
+    p.bn_running_mean = norm->running_mean; p.bn_running_var = norm->running_var;
+  } else {
+    p.linear_tiles = 1;
+  }
+  dispatch_fwd(p, g, dtype, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+  KD6D_CHECK_LAUNCH("kd6d_conv2d_fwd_norm");
   return KD6D_OK;
 }
 

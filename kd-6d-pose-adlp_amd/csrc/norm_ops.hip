@@ -7,11 +7,13 @@
 //   F.interpolate(nearest, x2) + add of the FPN top-down path, models/model.py:75-78
 //   F.relu between P6 and P7, models/model.py:101
 // All reductions accumulate in fp32; every kernel reads/writes 16-B granules.
+#include "kd6d_barrier.h"
 #include "kd6d_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
+using kd6d_detail::atomic_add_performed;
 
 // ---------------------------------------------------------------------------
 // Per-channel reductions over rows.  Thread t owns channel granule t % (C/EG);
@@ -21,15 +23,6 @@ constexpr int kThreads = 256;
 template <int O>
 __device__ __forceinline__ float row_ror_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + O, 0xF, 0xF, true));
-}
-
-// Device-scope float add whose RESULT the thread waits for: the value can only come back from where the add was
-// performed, so once it is here the add is visible to every later device-scope access of any workgroup.  The
-// kernels with an in-kernel barrier publish their partial sums with it (a returnless atomic is acknowledged
-// earlier than that and could be overtaken by the barrier's arrival on another memory channel).
-__device__ __forceinline__ void atomic_add_performed(float* p, float v) {
-  const float r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("" ::"v"(r));
 }
 
 // out[a]: `replicas` rows of C floats; this workgroup adds into row blockIdx.x % replicas (the rows are summed
@@ -75,51 +68,15 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
   }
 }
 
-// Spin limit of the in-kernel barriers below (~0.3 s): a barrier that cannot complete gives up, counts itself in
-// g_barrier_timeouts (kd6d_barrier_timeouts()) and lets the kernel drain -- wrong numbers instead of a hung GPU.
+// In-kernel barriers: kd6d_barrier.h (atomic_add_performed, group_barrier, grid_barrier, the residency argument).  The
+// kernels of this file count their give-ups here; the convolution epilogues add to the same word through its device
+// address (barrier_timeouts_device_ptr).
 __device__ unsigned int g_barrier_timeouts = 0;
-constexpr unsigned kSpinLimit = 1u << 21;
-
-// Arrive at `ctr` and wait until `need` workgroups have.  What crosses workgroups here is exchanged ONLY through
-// device-scope atomics (the partial sums, the counter) and device-scope atomic loads afterwards: those are performed
-// at the memory side, beyond the per-XCD L2s, so no L2 write-back / invalidate (what an agent-scope release /
-// acquire fence costs on a multi-XCD part, for every workgroup) is needed -- the partial sums are published with
-// atomic_add_performed (their results are back before the workgroup arrives), the workgroup-scope release and the
-// __syncthreads order the arrival behind them.
 __device__ __forceinline__ void group_barrier(unsigned int* ctr, unsigned need) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned it = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++it > kSpinLimit) { atomicAdd(&g_barrier_timeouts, 1u); break; }
-    }
-  }
-  __syncthreads();
+  kd6d_detail::group_barrier(ctr, need, &g_barrier_timeouts);
 }
-
-// All workgroups of the launch.  512 arrivals on one word would retire one after the other (~27 ns each, 14 us):
-// they are spread over kBarrierFan sub-counters (ctr[1..]) whose last arrivers report to ctr[0], the word everyone
-// polls.  ctr: KD6D_BARRIER_WORDS pre-zeroed words.
-constexpr unsigned kBarrierFan = 16;
 __device__ __forceinline__ void grid_barrier(unsigned int* ctr, unsigned nblocks) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned sub = blockIdx.x % kBarrierFan;
-    const unsigned in_sub = (nblocks - sub + kBarrierFan - 1) / kBarrierFan;
-    const unsigned old = __hip_atomic_fetch_add(ctr + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == in_sub) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned need = nblocks < kBarrierFan ? nblocks : kBarrierFan;
-    unsigned it = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++it > kSpinLimit) { atomicAdd(&g_barrier_timeouts, 1u); break; }
-    }
-  }
-  __syncthreads();
+  kd6d_detail::grid_barrier(ctr, blockIdx.x, nblocks, &g_barrier_timeouts);
 }
 
 // Row-tiled variant of the ownership rule: thread t owns channel granule t % cgs of row t / cgs
@@ -1583,6 +1540,15 @@ extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void
                                   dbeta, replicas));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd");
   return KD6D_OK;
+}
+
+unsigned int* kd6d_detail::barrier_timeouts_device_ptr() {
+  static unsigned int* ptr = []() {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_barrier_timeouts)) != hipSuccess) q = nullptr;
+    return reinterpret_cast<unsigned int*>(q);
+  }();
+  return ptr;
 }
 
 extern "C" int kd6d_barrier_timeouts(void) {

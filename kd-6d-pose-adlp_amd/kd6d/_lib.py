@@ -15,7 +15,10 @@ KD6D_F32 = 1
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 GN_STATS_READY, GN_WS_ZEROED = 1, 2
 MAX_SEG = 5
-ABI_VERSION = 6
+ABI_VERSION = 7
+NORM_GROUP, NORM_BATCH = 1, 2
+BN_FUSED_REPLICAS = 8
+NORM_MAX_CTILES = 8
 
 
 class Seg(ctypes.Structure):
@@ -41,6 +44,12 @@ class Levels(ctypes.Structure):
 class WgradItem(ctypes.Structure):
     _fields_ = [("geom", ConvGeom), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p),
                 ("dbias", ctypes.c_void_p)]
+
+
+class ConvNorm(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("groups", ctypes.c_int32), ("act", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("momentum", ctypes.c_float)] + [(n, ctypes.c_void_p) for n in (
+                    "gamma", "beta", "y", "stats", "counters", "running_mean", "running_var", "save_mean", "save_invstd")]
 
 
 MAX_GT = 4
@@ -75,6 +84,8 @@ SIGNATURES = {
     "kd6d_zero_regions": [ctypes.POINTER(ZeroList), _P, _I, _P],
     "kd6d_uniform_keys": [_P, _I64, _P, ctypes.c_uint64, _P],
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
+    "kd6d_conv2d_fwd_norm_fusable": [_G, _I, _I, _I],
+    "kd6d_conv2d_fwd_norm": [_G, _I, _P, _P, _P, _P, ctypes.POINTER(ConvNorm), _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
     "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],
     "kd6d_wgrad_group_supported": [_G, _I],

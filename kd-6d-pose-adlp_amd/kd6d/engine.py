@@ -141,6 +141,7 @@ class Conv:
         self.w = st.add(name + ".weight", "conv", (cout, cin, k, k), (self.cout_p, k, k, self.cin_p), trainable)
         self.b = st.add(name + ".bias", "vec", (cout,), (self.cout_p,), trainable) if bias else None
         self.geoms = {}
+        self._fusable = {}
         self.wt_off = None     # offset inside the dgrad-packed weight buffer
         net.convs.append(self)
 
@@ -177,6 +178,25 @@ class Conv:
         return ops.conv2d_fwd(g, x, self.weight(), out=out, ch_scale=scale, ch_shift=shift, act=act,
                               residual=residual, seg_scale=seg_scale, out_f32=out_f32, flops=self.flops(g),
                               stats=stats, stats_groups=stats_groups, workspace=self.net.workspace()), g
+
+    def norm_fusable(self, batch, levels, kind, groups=0):
+        """Does this layer take the conv + normalisation + activation launch (kd6d_conv2d_fwd_norm)?  Cached per
+        geometry and value of the `conv.fuse_norm` option."""
+        key = (batch, tuple(levels), kind, groups, self.net.dtype, ops.get_option("conv.fuse_norm"))
+        ok = self._fusable.get(key)
+        if ok is None:
+            ok = self._fusable[key] = ops.conv_norm_fusable(self.geom(batch, levels), self.net.dtype, kind, groups)
+        return ok
+
+    def fwd_norm(self, x, batch, levels, y, kind, gamma, beta, act, raw_out=None, groups=0, stats=None, **bn):
+        """conv (+ bias) -> normalisation -> activation in one launch; stats / counters live in the per-step zeroed arena."""
+        g = self.geom(batch, levels)
+        net = self.net
+        if stats is None:
+            stats = net.scratch(self.name + ".fstats", ops.conv_norm_stats_floats(g, kind, groups))
+        counters = net.scratch(self.name + ".fctr", ops.conv_norm_counter_words(g, kind))
+        return ops.conv2d_fwd_norm(g, x, self.weight(), y, kind, gamma, beta, stats, counters, act, raw_out=raw_out,
+                                   bias=self.bias(), groups=groups, flops=self.flops(g), **bn), g
 
     def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False, need_dw=True):
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
@@ -261,6 +281,16 @@ class ConvBlock:
         ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
         # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
         # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
+        if not pool and net.fuse_norm and self.conv.norm_fusable(batch, levels, ops.NORM_BATCH):
+            # conv -> batch statistics -> normalise + LeakyReLU as ONE launch (grid barrier in the epilogue): the
+            # statistics / apply launches and the re-read of the fp32 tensor go
+            raw = net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32)
+            z = net.buf(self.name + ".z", raw.shape, net.dtype)
+            _, g = self.conv.fwd_norm(x, batch, levels, z, ops.NORM_BATCH, st.storage(self.bn.gamma), st.storage(self.bn.beta),
+                                      ACT_LEAKY, raw_out=raw, eps=1e-5, momentum=0.1, running_mean=st.storage(self.bn.rm),
+                                      running_var=st.storage(self.bn.rv), save_mean=mean, save_invstd=invstd)
+            tape.append((self, x, raw, batch, tuple(levels), None))
+            return z, g.levels_out
         fused = geom.rows_out <= self.FUSE_STATS_MAX_ROWS
         raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
                                out=net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32),
@@ -322,6 +352,13 @@ class GroupNormReLU:
                         self.stats(batch, levels), flags=ops.GN_STATS_READY)
         return out
 
+    def fwd_fused(self, conv, x, batch, levels, out, raw_out=None):
+        """conv -> GroupNorm -> ReLU as one launch (the conv's epilogue); the statistics land where bwd expects them."""
+        st = self.net.store
+        conv.fwd_norm(x, batch, levels, out, ops.NORM_GROUP, st.storage(self.gamma), st.storage(self.beta), ACT_RELU,
+                      raw_out=raw_out, groups=self.groups, eps=1e-5, stats=self.stats(batch, levels))
+        return out
+
     def bwd_item(self, x, dz, batch, levels, dx):
         """The argument tuple of ops.gn_relu_bwd / gn_relu_bwd_pair for this layer."""
         net, st = self.net, self.net.store
@@ -367,6 +404,9 @@ class PoseNet:
         self.wgrad_group_wgs = 0
         self.wgrad_group_flush = "head_end"     # or "fpn_end" (GraphedKDStep picks by launch mode)
         self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
+        # conv + normalisation + activation as one launch where the library takes it (kd6d_conv2d_fwd_norm_fusable): the
+        # head towers (GroupNorm + ReLU) of both networks, the student's non-pooled ConvBlocks of stages 3-5 (BatchNorm)
+        self.fuse_norm = True
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
         self.pair_towers = 1
         self._side_rr = 0
@@ -679,15 +719,23 @@ class PoseNet:
             saved = {t: [] for t, _, _ in towers}
             for li in range(len(self.cls_tower)):
                 raws = {}
+                fuse = self.fuse_norm and all(tower[li][0].norm_fusable(B, levels_all, ops.NORM_GROUP, tower[li][1].groups)
+                                              for _, tower, _ in towers)
                 with ops.conv_pair():
                     for tname, tower, _ in towers:
                         conv, gn = tower[li]
-                        raws[tname], _ = conv.fwd(xs[tname], B, levels_all, out_f32=True,
-                                                  out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32),
-                                                  stats=gn.stats(B, levels_all), stats_groups=gn.groups)
+                        raws[tname] = self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32)
+                        if fuse:
+                            gn.fwd_fused(conv, xs[tname], B, levels_all, self.buf("%s.act%d" % (tname, li), (r, oc)),
+                                         raw_out=raws[tname])
+                        else:
+                            conv.fwd(xs[tname], B, levels_all, out_f32=True, out=raws[tname],
+                                     stats=gn.stats(B, levels_all), stats_groups=gn.groups)
                 for tname, tower, _ in towers:
                     gn = tower[li][1]
-                    y = gn.fwd(raws[tname], B, levels_all, out=self.buf("%s.act%d" % (tname, li), (r, oc)))
+                    y = self.buf("%s.act%d" % (tname, li), (r, oc))
+                    if not fuse:
+                        gn.fwd(raws[tname], B, levels_all, out=y)
                     saved[tname].append((xs[tname], raws[tname]))
                     xs[tname] = y
             for tname, tower, final in towers:
@@ -701,10 +749,16 @@ class PoseNet:
             x = head_in
             saved = []
             for li, (conv, gn) in enumerate(tower):
-                raw, _ = conv.fwd(x, B, levels_all, out_f32=True,
-                                  out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32),
-                                  stats=gn.stats(B, levels_all), stats_groups=gn.groups)
-                y = gn.fwd(raw, B, levels_all, out=self.buf("%s.act%d" % (tname, li), (r, oc)))
+                y = self.buf("%s.act%d" % (tname, li), (r, oc))
+                if self.fuse_norm and conv.norm_fusable(B, levels_all, ops.NORM_GROUP, gn.groups):
+                    # eval mode (the frozen teacher): the fp32 pre-normalisation tensor is not even stored
+                    raw = self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32) if self.training else None
+                    gn.fwd_fused(conv, x, B, levels_all, y, raw_out=raw)
+                else:
+                    raw, _ = conv.fwd(x, B, levels_all, out_f32=True,
+                                      out=self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32),
+                                      stats=gn.stats(B, levels_all), stats_groups=gn.groups)
+                    gn.fwd(raw, B, levels_all, out=y)
                 saved.append((x, raw))
                 x = y
             seg = self.store.storage(self.scales) if tname == "pose" else None

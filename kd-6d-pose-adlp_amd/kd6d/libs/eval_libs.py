@@ -2,16 +2,16 @@
 
 `valid()` runs the model in eval mode over a loader of (images, targets, meta_infos), keeps the most confident
 pose per image (`new_p[0][:-1]`: score, class, R, T -- the 2D points are dropped as in the reference) and scores
-the collection with `evaluate_pose_predictions`.  Not rebuilt here (the BOP reader): loading
-meshes / 3D boxes from disk (`load_bop_meshes`, `load_bbox_3d`) and `remap_predictions` (re-solving the pose for
-the original camera matrix of a resized frame) -- meshes are passed in, and predictions are scored in the
-internal camera frame they were solved in.
+the collection with `evaluate_pose_predictions`.  As in eval_libs.py:69-76 every prediction is first re-solved for the
+frame's own camera (`remap_predictions`: identity when the frame carries the internal camera, which is what the
+synthetic loaders and frames stored at the internal resolution do).  Meshes are passed in by the caller
+(kd6d.libs.train_libs.dataset_meshes / the synthetic loaders).
 """
 import numpy as np
 import torch
 
 from .distributed import get_rank
-from .evaluate import evaluate_pose_predictions
+from .evaluate import evaluate_pose_predictions, remap_predictions
 
 
 class _Mesh:
@@ -31,6 +31,13 @@ def valid(cfg, steps, loader, model, device, meshes, logger=None):
             images = images.to(device)
         pred, _ = model(images, targets=targets)
         for m, p in zip(meta_infos, pred):
+            if len(p) and "K" in m and cfg.get("INPUT", {}).get("INTERNAL_K") is not None and \
+                    not np.allclose(np.asarray(m["K"], np.float64).reshape(3, 3),
+                                    np.asarray(cfg["INPUT"]["INTERNAL_K"], np.float64).reshape(3, 3)):
+                kp3d = targets.kp3d[0].cpu().numpy() if hasattr(targets, "kp3d") else None     # (n_class, 8, 3) box corners
+                if kp3d is not None:            # eval_libs.py:71-76: poses solved for the internal camera -> the frame's own
+                    p = remap_predictions(cfg["INPUT"]["INTERNAL_K"], cfg["INPUT"].get("INTERNAL_WIDTH"),
+                                          cfg["INPUT"].get("INTERNAL_HEIGHT"), kp3d, m, p)
             best = [list(p[0][:-1])] if len(p) else []
             preds[m["path"]] = {"meta": m, "pred": best}
     model.train(was_training)

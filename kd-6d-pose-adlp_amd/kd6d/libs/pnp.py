@@ -177,3 +177,39 @@ def solve_pnp_ransac(xyz, uv, K, reproj_err=5.0, iters=300, seed=0):
     if cnt < 6 or not (np.all(np.isfinite(R)) and np.all(np.isfinite(T))):
         return False, None, None, None
     return True, R.astype(np.float32), T.reshape(3, 1).astype(np.float32), np.nonzero(inl)[0]
+
+
+def solve_pnp(xyz, uv, K):
+    """cv2.solvePnP without RANSAC for clean correspondences (libs/utils.py:511 uses SOLVEPNP_EPNP): direct linear
+    transform + Gauss-Newton.  -> (ok, R (3,3), T (3,1))."""
+    xyz = np.asarray(xyz, np.float64).reshape(-1, 3)
+    uv = np.asarray(uv, np.float64).reshape(-1, 2)
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    if xyz.shape[0] < 6 or uv.shape[0] != xyz.shape[0] or not (np.all(np.isfinite(xyz)) and np.all(np.isfinite(uv))):
+        return False, None, None
+    fit = _dlt(np.linalg.inv(K), xyz, uv)
+    if fit is None:
+        return False, None, None
+    R, T = _refine(K, fit[0], fit[1], xyz, uv, iters=20)
+    if not (np.all(np.isfinite(R)) and np.all(np.isfinite(T))):
+        return False, None, None
+    return True, R, np.asarray(T, np.float64).reshape(3, 1)
+
+
+def remap_pose(srcK, srcR, srcT, pt3d, dstK, transM):
+    """libs/utils.py:504-526: the pose that, seen through dstK, projects the object's 3D points where (srcR, srcT) seen
+    through srcK and mapped by the homography transM put them.  -> (newR, newT (3,1), mean reprojection difference in
+    pixels), or (srcR, srcT, -1) when no pose is found."""
+    pt3d = np.asarray(pt3d, np.float64).reshape(-1, 3)
+    srcR = np.asarray(srcR, np.float64).reshape(3, 3)
+    srcT = np.asarray(srcT, np.float64).reshape(3, 1)
+    dstK = np.asarray(dstK, np.float64).reshape(3, 3)
+    pts = np.asarray(transM, np.float64) @ (np.asarray(srcK, np.float64).reshape(3, 3) @ (srcR @ pt3d.T + srcT))
+    xy2d = np.stack([pts[0] / (pts[2] + 1e-8), pts[1] / (pts[2] + 1e-8)], 1)
+    ok, newR, newT = solve_pnp(pt3d, xy2d, dstK)
+    if not ok:
+        print("Error in pose remapping!")
+        return srcR, srcT, -1
+    new = dstK @ (newR @ pt3d.T + newT)
+    new_xy = np.stack([new[0] / (new[2] + 1e-8), new[1] / (new[2] + 1e-8)], 1)
+    return newR, newT, float(np.linalg.norm(xy2d - new_xy, axis=1).mean())

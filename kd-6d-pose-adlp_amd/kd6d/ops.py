@@ -126,6 +126,48 @@ def conv2d_fwd(geom, x, w, out=None, ch_scale=None, ch_shift=None, act=ACT_NONE,
     return out
 
 
+NORM_GROUP, NORM_BATCH = _lib.NORM_GROUP, _lib.NORM_BATCH
+
+
+def conv_norm_fusable(geom, dtype, kind, groups=0):
+    """kd6d_conv2d_fwd_norm_fusable: does this layer take the conv + normalisation + activation launch?"""
+    return bool(lib.kd6d_conv2d_fwd_norm_fusable(geom.ref, dt_code(dtype), int(kind), int(groups)))
+
+
+def conv_norm_counter_words(geom, kind):
+    """32-bit words of the pre-zeroed barrier counters of conv2d_fwd_norm (kd6d.h)."""
+    return BARRIER_WORDS if kind == NORM_BATCH else len(geom.levels_in) * geom.batch * _lib.NORM_MAX_CTILES
+
+
+def conv_norm_stats_floats(geom, kind, groups=0):
+    if kind == NORM_BATCH:
+        return _lib.BN_FUSED_REPLICAS * 2 * geom.cout
+    return len(geom.levels_in) * geom.batch * groups * 2
+
+
+def conv2d_fwd_norm(geom, x, w, y, kind, gamma, beta, stats, counters, act, raw_out=None, bias=None, groups=0, eps=1e-5,
+                    momentum=0.1, running_mean=None, running_var=None, save_mean=None, save_invstd=None, flops=0):
+    """conv (+ bias) -> GroupNorm / train-mode BatchNorm -> activation as ONE launch (kd6d_conv2d_fwd_norm).
+    y: (rows_out, cout) in x.dtype; raw_out: optional fp32 pre-normalisation tensor for the backward pass;
+    stats / counters: pre-zeroed (conv_norm_stats_floats / conv_norm_counter_words)."""
+    assert x.shape == (geom.rows_in, geom.cin) and w.dtype == x.dtype
+    assert y.shape == (geom.rows_out, geom.cout) and y.dtype == x.dtype
+    assert raw_out is None or (raw_out.shape == y.shape and raw_out.dtype == torch.float32)
+    assert stats.dtype == torch.float32 and stats.numel() >= conv_norm_stats_floats(geom, kind, groups)
+    assert counters.numel() >= conv_norm_counter_words(geom, kind) and counters.element_size() == 4
+    n = _lib.ConvNorm()
+    n.kind, n.groups, n.act, n.eps, n.momentum = int(kind), int(groups), int(act), float(eps), float(momentum)
+    for name, t in (("gamma", gamma), ("beta", beta), ("y", y), ("stats", stats), ("counters", counters),
+                    ("running_mean", running_mean), ("running_var", running_var), ("save_mean", save_mean),
+                    ("save_invstd", save_invstd)):
+        assert t is None or (t.is_cuda and t.is_contiguous())
+        setattr(n, name, t.data_ptr() if t is not None else None)
+    with _Timed("conv_fwd", flops, geom):
+        check(lib.kd6d_conv2d_fwd_norm(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(w), _ptr(raw_out), _ptr(bias),
+                                       ctypes.byref(n), _stream()), "kd6d_conv2d_fwd_norm")
+    return y
+
+
 def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     assert dy.shape == (geom.rows_out, geom.cout), (dy.shape, geom.rows_out, geom.cout)
     assert wt.dtype == dy.dtype and wt.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin

@@ -119,3 +119,38 @@ def test_symmetry_handling_known_answers():
     np.testing.assert_allclose(a, [np.fmod(2.5, np.pi), 0.1, 0.4], atol=1e-6)
     with pytest.raises(ValueError):
         pose_symmetry_handling(R, ["Q", 0])
+
+
+def test_remap_predictions_known_answers():
+    """libs/evaluate.py:174-197 / libs/utils.py:504-526: a pose solved for the internal camera, re-solved for the frame's
+    own camera through the homography K * K_int^-1.  Known answers: the identity when both cameras agree; for a camera
+    with another focal length / principal point the remapped pose must reproject the object's points (through the new
+    camera) exactly where the homography puts the old projections; K * K_int^-1 maps a pixel to the pixel of the SAME
+    ray in the other camera, so the pose itself does not change (focal length x 1.25: same R, same depth)."""
+    from kd6d.libs.evaluate import remap_predictions
+    from kd6d.libs.pnp import project, remap_pose, rodrigues
+    rng = np.random.default_rng(4)
+    K_int = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])
+    kp = (rng.uniform(-1, 1, (15, 8, 3)) * 60.0)
+    R = rodrigues(np.array([0.3, -0.7, 0.2]))
+    T = np.array([[25.0], [-40.0], [900.0]])
+    pred = [[0.9, 3, R, T, np.zeros((8, 2))]]
+    same = remap_predictions(K_int.reshape(-1).tolist(), 640, 480, kp, {"K": K_int}, pred)
+    np.testing.assert_allclose(same[0][2], R, atol=1e-8)
+    np.testing.assert_allclose(same[0][3], T, atol=1e-5)
+    assert same[0][0] == 0.9 and same[0][1] == 3
+    # focal length x 1.25, same principal point: depth scales with the focal length
+    K2 = K_int.copy()
+    K2[0, 0] *= 1.25; K2[1, 1] *= 1.25
+    out = remap_predictions(K_int.reshape(-1).tolist(), 640, 480, kp, {"K": K2}, pred)
+    np.testing.assert_allclose(out[0][2], R, atol=2e-3)
+    np.testing.assert_allclose(out[0][3][2, 0], 900.0, rtol=2e-3)       # K2 * K_int^-1 maps u -> the same ray: same pose
+    # a different camera altogether: reprojection consistency
+    K3 = np.array([[610.0, 0, 300.0], [0, 590.0, 260.0], [0, 0, 1.0]])
+    newR, newT, err = remap_pose(K_int, R, T, kp[3], K3, K3 @ np.linalg.inv(K_int))
+    assert err < 1e-3
+    uv_old, _ = project(K_int, R, T.reshape(3), kp[3])
+    h = (K3 @ np.linalg.inv(K_int)) @ np.concatenate([uv_old, np.ones((8, 1))], 1).T
+    uv_new, z = project(K3, newR, newT.reshape(3), kp[3])
+    np.testing.assert_allclose(uv_new, (h[:2] / h[2]).T, atol=1e-3)
+    assert np.all(z > 0)

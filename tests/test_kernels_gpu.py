@@ -1055,3 +1055,167 @@ def test_uniform_keys_counter_based(gpu_device):
         assert float((a == other).float().mean()) < 1e-3
         assert abs(float(((a - 0.5) * (other - 0.5)).mean())) < 1e-3          # uncorrelated streams
     assert float((a[1:] == a[:-1]).float().mean()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution + normalisation + activation as ONE launch (kd6d_conv2d_fwd_norm)
+# ---------------------------------------------------------------------------------------------------------
+FUSED_GN_CASES = [
+    # (B, C, levels, halo-kernel option: -1 = the dispatcher's choice, 0 = generic / LDS-DMA kernels)
+    (2, 128, [(32, 32), (16, 16), (8, 8), (4, 4)], -1),          # student towers, small batch: keys span several tiles
+    (16, 128, [(32, 32), (16, 16), (8, 8), (4, 4)], -1),         # ... at the benchmark batch (128x128 twin tiles)
+    (16, 256, [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)], -1),  # teacher towers: two channel tiles, 2x2 level
+    (3, 128, [(15, 20), (8, 10), (4, 5)], -1),                   # odd maps (full-frame levels)
+    (2, 256, [(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)], -1),  # maps 80 wide: not the halo kernel
+    (3, 128, [(12, 12), (6, 6), (3, 3)], 0),                     # halo kernel off
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", FUSED_GN_CASES, ids=[str(i) for i in range(len(FUSED_GN_CASES))])
+def test_conv_fwd_norm_group(gpu_device, dtype, case):
+    """models/model.py:395-417,438-451: tower Conv2d(3x3, bias) -> GroupNorm(32) -> ReLU over all pyramid levels, one
+    launch (window barrier per (level, image) in the conv epilogue).  Against torch on the CPU, and against the two-launch
+    path (kd6d_conv2d_fwd with fused statistics + kd6d_gn_relu_fwd): the same statistics up to atomic order."""
+    ops = _ops()
+    dev = gpu_device
+    B, C, levels, halo = case
+    if dtype == torch.float32 and B * sum(h * w for h, w in levels) > 8000:
+        pytest.skip("fp32 mode runs the exact-fp32 MFMA chain: covered by the small cases")
+    _option("conv.halo", halo)
+    G = 32
+    gen = torch.Generator().manual_seed(C + B)
+    geom = ops.Geom(B, C, C, 3, 1, 1, levels)
+    xs = [round_to(torch.randn(B, C, h, w, generator=gen), dtype) for (h, w) in levels]
+    w = round_to(torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5, dtype)
+    bias = torch.randn(C, generator=gen) * 0.1
+    gamma = torch.rand(C, generator=gen) + 0.5
+    beta = torch.randn(C, generator=gen) * 0.2
+    assert ops.conv_norm_fusable(geom, dtype, ops.NORM_GROUP, G)
+    xp = pack_levels(xs, dtype).to(dev)
+    wk = w_to_krsc(w, dtype).to(dev)
+    raws, ys = [], []
+    for x in xs:
+        raw = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+        raws.append(raw)
+        ys.append(F.relu(F.group_norm(raw, G, gamma.double(), beta.double(), 1e-5)))
+    y = torch.empty(geom.rows_out, C, dtype=dtype, device=dev)
+    raw_out = torch.empty(geom.rows_out, C, dtype=torch.float32, device=dev)
+    for with_raw in (True, False):          # eval-mode callers do not store the pre-normalisation tensor
+        stats = torch.zeros(ops.conv_norm_stats_floats(geom, ops.NORM_GROUP, G), device=dev)
+        ctr = torch.zeros(ops.conv_norm_counter_words(geom, ops.NORM_GROUP), dtype=torch.int32, device=dev)
+        y.fill_(7.0)
+        ops.conv2d_fwd_norm(geom, xp, wk, y, ops.NORM_GROUP, gamma.to(dev), beta.to(dev), stats, ctr, ops.ACT_RELU,
+                            raw_out=raw_out if with_raw else None, bias=bias.to(dev), groups=G)
+        torch.cuda.synchronize()
+        assert ops.lib.kd6d_barrier_timeouts() == 0
+        for gl, ref in zip(unpack_levels(y.float().cpu(), B, levels), ys):
+            torch.testing.assert_close(gl.double(), ref, **_tol(dtype, stored=True))
+    for gl, ref in zip(unpack_levels(raw_out.cpu(), B, levels), raws):
+        torch.testing.assert_close(gl.double(), ref, rtol=2e-4, atol=2e-4)
+    # the two-launch path on the same inputs
+    stats2 = torch.zeros_like(stats)
+    raw2 = ops.conv2d_fwd(geom, xp, wk, ch_shift=bias.to(dev), out_f32=True, stats=stats2, stats_groups=G)
+    y2 = torch.empty_like(y)
+    ops.gn_relu_fwd(raw2, y2, [h * w_ for (h, w_) in levels], B, G, gamma.to(dev), beta.to(dev), 1e-5, stats2,
+                    flags=ops.GN_STATS_READY)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(stats.cpu(), stats2.cpu(), rtol=1e-4, atol=1e-3)        # what kd6d_gn_relu_bwd reads
+    d = (y.float() - y2.float()).abs()
+    ulp = y2.float().abs() * 2.0 ** -7 + 1e-6 if dtype == torch.bfloat16 else y2.float().abs() * 1e-5 + 1e-5
+    assert bool((d <= ulp).all()), float(d.max())
+    assert float((d > 0).float().mean()) < 1e-2          # a few elements one rounding step apart
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # (B, Cin, Cout, k, (H, W)): the student's non-pooled ConvBlocks of stages 3-5 (tiny_h / tiny) + odd sizes
+    (16, 64, 16, 1, (32, 32)), (16, 128, 32, 1, (16, 16)), (16, 32, 256, 3, (16, 16)), (16, 256, 64, 1, (16, 16)),
+    (16, 64, 512, 3, (16, 16)), (2, 16, 128, 3, (15, 20)), (3, 128, 16, 1, (7, 9)),
+])
+def test_conv_fwd_norm_batch(gpu_device, dtype, case):
+    """backbone/common.py:316-324 in train mode: Conv2d(no bias) -> BatchNorm2d (batch statistics, running-stat update)
+    -> LeakyReLU(0.1) as one launch (grid barrier in the conv epilogue), against torch on the CPU."""
+    ops = _ops()
+    dev = gpu_device
+    B, Cin, Cout, k, (H, W) = case
+    if dtype == torch.float32 and B * H * W * Cout * Cin * k * k > 3e9:
+        pytest.skip("fp32 mode: covered by the smaller cases")
+    gen = torch.Generator().manual_seed(Cin * 7 + Cout)
+    geom = ops.Geom(B, Cin, Cout, k, 1, k // 2, [(H, W)])
+    if not ops.conv_norm_fusable(geom, dtype, ops.NORM_BATCH):
+        pytest.skip("not a fused geometry for this precision (the engine then runs conv + bn_train_fwd)")
+    x = round_to(torch.randn(B, Cin, H, W, generator=gen), dtype)
+    w = round_to(torch.randn(Cout, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5, dtype)
+    gamma = torch.rand(Cout, generator=gen) + 0.5
+    beta = torch.randn(Cout, generator=gen) * 0.2
+    rm0 = torch.randn(Cout, generator=gen) * 0.1
+    rv0 = torch.rand(Cout, generator=gen) + 0.5
+    raw = F.conv2d(x.double(), w.double(), padding=k // 2)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    yr = F.leaky_relu(F.batch_norm(raw, rm, rv, gamma.double(), beta.double(), True, 0.1, 1e-5), 0.1)
+    xp = pack_levels([x], dtype).to(dev)
+    y = torch.empty(geom.rows_out, Cout, dtype=dtype, device=dev)
+    raw_out = torch.empty(geom.rows_out, Cout, dtype=torch.float32, device=dev)
+    stats = torch.zeros(ops.conv_norm_stats_floats(geom, ops.NORM_BATCH), device=dev)
+    ctr = torch.zeros(ops.conv_norm_counter_words(geom, ops.NORM_BATCH), dtype=torch.int32, device=dev)
+    rmd, rvd = rm0.to(dev), rv0.to(dev)
+    mean = torch.empty(Cout, device=dev); invstd = torch.empty(Cout, device=dev)
+    ops.conv2d_fwd_norm(geom, xp, w_to_krsc(w, dtype).to(dev), y, ops.NORM_BATCH, gamma.to(dev), beta.to(dev), stats, ctr,
+                        ops.ACT_LEAKY, raw_out=raw_out, running_mean=rmd, running_var=rvd, save_mean=mean, save_invstd=invstd)
+    torch.cuda.synchronize()
+    assert ops.lib.kd6d_barrier_timeouts() == 0
+    torch.testing.assert_close(unpack_levels(raw_out.cpu(), B, [(H, W)])[0].double(), raw, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(unpack_levels(y.float().cpu(), B, [(H, W)])[0].double(), yr, **_tol(dtype, stored=True))
+    m_ref = raw.mean((0, 2, 3)); v_ref = raw.var((0, 2, 3), unbiased=False)
+    torch.testing.assert_close(mean.cpu().double(), m_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(invstd.cpu().double(), torch.rsqrt(v_ref + 1e-5), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(rmd.cpu().double(), rm, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rvd.cpu().double(), rv, rtol=1e-3, atol=1e-4)
+
+
+def test_conv_fwd_norm_under_repetition(gpu_device):
+    """300 back-to-back launches of each fused form with fresh counters, the GroupNorm one on two streams at once
+    (a window-barrier launch beside a grid-barrier launch is what the step runs): no wait may give up and every
+    launch must give the first one's result."""
+    ops = _ops()
+    dev = gpu_device
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(3)
+    B = 16
+    levels = [(32, 32), (16, 16), (8, 8), (4, 4)]
+    gg = ops.Geom(B, 128, 128, 3, 1, 1, levels)
+    gb = ops.Geom(B, 32, 256, 3, 1, 1, [(16, 16)])
+    xg = torch.randn(gg.rows_in, 128, generator=gen).to(dtype).to(dev)
+    wg = (torch.randn(128 * 9 * 128, generator=gen) / 34.0).to(dtype).to(dev)
+    xb = torch.randn(gb.rows_in, 32, generator=gen).to(dtype).to(dev)
+    wb = (torch.randn(256 * 9 * 32, generator=gen) / 17.0).to(dtype).to(dev)
+    ones = {c: torch.ones(c, device=dev) for c in (128, 256)}
+    zeros = {c: torch.zeros(c, device=dev) for c in (128, 256)}
+    n = 300
+    sg = torch.zeros(n, ops.conv_norm_stats_floats(gg, ops.NORM_GROUP, 32), device=dev)
+    cg = torch.zeros(n, ops.conv_norm_counter_words(gg, ops.NORM_GROUP), dtype=torch.int32, device=dev)
+    sb = torch.zeros(n, ops.conv_norm_stats_floats(gb, ops.NORM_BATCH), device=dev)
+    cb = torch.zeros(n, ops.conv_norm_counter_words(gb, ops.NORM_BATCH), dtype=torch.int32, device=dev)
+    yg = [torch.empty(gg.rows_out, 128, dtype=dtype, device=dev) for _ in range(2)]
+    yb = [torch.empty(gb.rows_out, 256, dtype=dtype, device=dev) for _ in range(2)]
+    mean = torch.empty(256, device=dev); invstd = torch.empty(256, device=dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = 0
+    for i in range(n):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.conv2d_fwd_norm(gg, xg, wg, yg[min(i, 1)], ops.NORM_GROUP, ones[128], zeros[128], sg[i], cg[i], ops.ACT_RELU,
+                                groups=32)
+        ops.conv2d_fwd_norm(gb, xb, wb, yb[min(i, 1)], ops.NORM_BATCH, ones[256], zeros[256], sb[i], cb[i], ops.ACT_LEAKY,
+                            save_mean=mean, save_invstd=invstd)
+        torch.cuda.current_stream().wait_stream(side)
+        if i >= 1 and i % 50 == 0:
+            torch.cuda.synchronize()
+            for a, b_ in ((yg[0], yg[1]), (yb[0], yb[1])):
+                d = (a.float() - b_.float()).abs()
+                bad += int((d > a.float().abs() * 2.0 ** -6 + 1e-3).sum())
+    torch.cuda.synchronize()
+    assert ops.lib.kd6d_barrier_timeouts() == 0
+    assert bad == 0
