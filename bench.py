@@ -69,6 +69,9 @@ def parse():
                         "the all-reduce between the two graphs, barriers) on one GPU")
     p.add_argument("--opt", action="append", default=[],
                    help="kernel-selection option name=value (kd6d_set_option, include/kd6d.h): tuning aid for A/B runs")
+    p.add_argument("--fuse-norm", type=str, default="", choices=["", "none", "teacher", "student", "both"],
+                   help="A/B aid: which network's convolutions take the conv + normalisation launch (kd6d_conv2d_fwd_norm); "
+                        "default = the engine's measured choice")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` timings (child runs of the other configs)")
     p.add_argument("--no-launch-events", action="store_true",
@@ -266,6 +269,9 @@ def main():
     student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
     student.net.reset_parameters(seed=1)
     student = student.to(dev).train()
+    if args.fuse_norm:
+        teacher.net.fuse_norm = args.fuse_norm in ("teacher", "both")
+        student.net.fuse_norm = args.fuse_norm in ("student", "both")
     D.SINGLE_RANK_EXCHANGE = bool(args.rccl_single_rank)
     route = D.init_exchange() if use_pg else "none"      # kd6d_comm_* over librccl (include/kd6d.h)
     if use_pg:

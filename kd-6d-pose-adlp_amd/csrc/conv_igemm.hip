@@ -1538,7 +1538,8 @@ int set_stats(const kd6d_conv_geom* g, ConvParams& p, float* stats, int stats_gr
 // Would kd6d_conv2d_fwd_norm take the fused path?  Dry run of the dispatch with the fields that steer it set the way
 // the real call sets them, then the residency rule of kd6d_barrier.h.
 bool norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups, ConvParams& p, LaunchPlan& plan) {
-  if (kd6d_opt(KD6D_OPT_CONV_FUSE_NORM) == 0) return false;
+  // option conv.fuse_norm: bit 0 = GroupNorm launches, bit 1 = BatchNorm launches
+  if (((int)kd6d_opt(KD6D_OPT_CONV_FUSE_NORM) & (kind == KD6D_NORM_GROUP ? 1 : 2)) == 0) return false;
   if (fwd_params(g, dtype, "kd6d_conv2d_fwd_norm", p) != KD6D_OK) return false;
   static float dummy;
   if (set_stats(g, p, &dummy, kind == KD6D_NORM_GROUP ? groups : 0, "kd6d_conv2d_fwd_norm") != KD6D_OK) return false;

@@ -50,7 +50,7 @@ enum Kd6dOption {
   KD6D_OPT_GN_ONEPASS,         // 1 | 0: the two-launch GN backward
   KD6D_OPT_SINKHORN_LANES,     // 1 | 0: every set on the general (one softmin after the other) path
   KD6D_OPT_CONV_HALO_PAIRING,  // 1 | 0: maps <= 32 wide keep the double-buffered (one workgroup per CU) halo tiles
-  KD6D_OPT_CONV_FUSE_NORM,     // 1 | 0: kd6d_conv2d_fwd_norm_fusable reports 0 for every geometry (conv and normalisation as separate launches)
+  KD6D_OPT_CONV_FUSE_NORM,     // bit 0: GroupNorm, bit 1: BatchNorm geometries may take the fused launch (0: kd6d_conv2d_fwd_norm_fusable reports 0)
   KD6D_OPT_COUNT
 };
 long long kd6d_opt(int id);

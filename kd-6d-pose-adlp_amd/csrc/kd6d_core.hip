@@ -24,9 +24,9 @@ struct OptRow { const char* name; long long def; };
 const OptRow kOptRows[KD6D_OPT_COUNT] = {
     {"conv.halo", -1},  {"conv.smallc", -1},       {"conv.splitk", -1}, {"conv.tile", -1},     {"wgrad.small", -1},
     {"bn.onepass", 1},  {"bn.onepass_max", 65536}, {"gn.onepass", 1},   {"sinkhorn.lanes", 1},
-    {"conv.halo_pairing", 1}, {"conv.fuse_norm", 1},
+    {"conv.halo_pairing", 1}, {"conv.fuse_norm", 3},
 };
-long long g_opt[KD6D_OPT_COUNT] = {-1, -1, -1, -1, -1, 1, 65536, 1, 1, 1, 1};
+long long g_opt[KD6D_OPT_COUNT] = {-1, -1, -1, -1, -1, 1, 65536, 1, 1, 1, 3};
 int opt_index(const char* name) {
   if (!name) return -1;
   for (int i = 0; i < KD6D_OPT_COUNT; ++i)

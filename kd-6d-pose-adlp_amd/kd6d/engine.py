@@ -281,7 +281,7 @@ class ConvBlock:
         ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
         # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
         # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
-        if not pool and net.fuse_norm and self.conv.norm_fusable(batch, levels, ops.NORM_BATCH):
+        if not pool and net.fuse_norm_on() and self.conv.norm_fusable(batch, levels, ops.NORM_BATCH):
             # conv -> batch statistics -> normalise + LeakyReLU as ONE launch (grid barrier in the epilogue): the
             # statistics / apply launches and the re-read of the fp32 tensor go
             raw = net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32)
@@ -404,9 +404,13 @@ class PoseNet:
         self.wgrad_group_wgs = 0
         self.wgrad_group_flush = "head_end"     # or "fpn_end" (GraphedKDStep picks by launch mode)
         self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
-        # conv + normalisation + activation as one launch where the library takes it (kd6d_conv2d_fwd_norm_fusable): the
-        # head towers (GroupNorm + ReLU) of both networks, the student's non-pooled ConvBlocks of stages 3-5 (BatchNorm)
-        self.fuse_norm = True
+        # conv + normalisation + activation as one launch (kd6d_conv2d_fwd_norm: in-kernel barrier in the conv epilogue).
+        # None = the measured choice: the head towers of an EVAL-mode network (the frozen teacher: the fp32
+        # pre-normalisation tensor is then not even stored, +0.4 ... +1.1 % on the step) but NOT the training network --
+        # a workgroup that waits at a barrier keeps its LDS and wave slots while the other stream's kernels could use
+        # them: student towers fused -3 %, student BatchNorm blocks fused -1.2 % (interleaved runs on one box,
+        # profiles/README.md round 3); a kernel boundary is the cheaper barrier when two streams share the device.
+        self.fuse_norm = None
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
         self.pair_towers = 1
         self._side_rr = 0
@@ -544,6 +548,9 @@ class PoseNet:
 
     SCRATCH_FLOATS = 1 << 22
     WORKSPACE_BYTES = 64 << 20      # split-K partial slabs (fp32) of the few-tile / long-K layers
+
+    def fuse_norm_on(self):
+        return (not self.training) if self.fuse_norm is None else bool(self.fuse_norm)
 
     def next_side_stream(self):
         if self.side_streams:
@@ -719,7 +726,7 @@ class PoseNet:
             saved = {t: [] for t, _, _ in towers}
             for li in range(len(self.cls_tower)):
                 raws = {}
-                fuse = self.fuse_norm and all(tower[li][0].norm_fusable(B, levels_all, ops.NORM_GROUP, tower[li][1].groups)
+                fuse = self.fuse_norm_on() and all(tower[li][0].norm_fusable(B, levels_all, ops.NORM_GROUP, tower[li][1].groups)
                                               for _, tower, _ in towers)
                 with ops.conv_pair():
                     for tname, tower, _ in towers:
@@ -750,7 +757,7 @@ class PoseNet:
             saved = []
             for li, (conv, gn) in enumerate(tower):
                 y = self.buf("%s.act%d" % (tname, li), (r, oc))
-                if self.fuse_norm and conv.norm_fusable(B, levels_all, ops.NORM_GROUP, gn.groups):
+                if self.fuse_norm_on() and conv.norm_fusable(B, levels_all, ops.NORM_GROUP, gn.groups):
                     # eval mode (the frozen teacher): the fp32 pre-normalisation tensor is not even stored
                     raw = self.buf("%s.raw%d" % (tname, li), (r, oc), torch.float32) if self.training else None
                     gn.fwd_fused(conv, x, B, levels_all, y, raw_out=raw)

