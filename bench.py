@@ -72,6 +72,9 @@ def parse():
     p.add_argument("--fuse-norm", type=str, default="", choices=["", "none", "teacher", "student", "both"],
                    help="A/B aid: which network's convolutions take the conv + normalisation launch (kd6d_conv2d_fwd_norm); "
                         "default = the engine's measured choice")
+    p.add_argument("--no-bn-on-load", action="store_true",
+                   help="A/B aid: the student's in-stage BatchNorm + LeakyReLU as separate launches instead of applied "
+                        "by the next block's convolution while it loads (kd6d_conv2d_fwd_block)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` timings (child runs of the other configs)")
     p.add_argument("--no-launch-events", action="store_true",
@@ -269,6 +272,8 @@ def main():
     student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
     student.net.reset_parameters(seed=1)
     student = student.to(dev).train()
+    if args.no_bn_on_load or os.environ.get("KD6D_BN_ON_LOAD") == "0":      # (env: a one-off A/B run of round 3)
+        student.net.bn_on_load = False
     if args.fuse_norm:
         teacher.net.fuse_norm = args.fuse_norm in ("teacher", "both")
         student.net.fuse_norm = args.fuse_norm in ("student", "both")
@@ -477,6 +482,8 @@ def bench_dense(args, out_fd):
         dist.init_process_group(backend="nccl", init_method="env://")
     from kd6d import ops
     from kd6d.arguments.argument_kd import load_yaml
+    for kv in args.opt:
+        ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     kd = load_yaml(os.path.join(HERE, "configs", "dense16d.yaml"))["KD_DENSE"]
     N = M = int(kd["GRID"][0]) * int(kd["GRID"][1])
     D = int(kd["CODE_DIM"])

@@ -138,6 +138,30 @@ int kd6d_conv2d_fwd_norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, i
 int kd6d_conv2d_fwd_norm(const kd6d_conv_geom* g, int dtype, const void* x, const void* w, void* raw_out,
                          const float* bias, const kd6d_conv_norm* norm, void* stream);
 
+/* The convolution of a train-mode ConvBlock (backbone/common.py:316-324: Conv2d(no bias) -> BatchNorm2d -> LeakyReLU):
+ * y_raw (rows_out, cout) fp32 = conv(input, w), with the batch sums of y_raw accumulated into `stats` (pre-zeroed,
+ * stats_replicas rows of {sum[cout], sumsq[cout]}; workgroup b adds to row b % stats_replicas, consumers add the rows).
+ * The input is either x (rows_in, cin) in `dtype` (bn == NULL), or -- bn != NULL -- the PREVIOUS block's fp32 conv
+ * output, whose BatchNorm + activation is applied while it is loaded (no separate normalise launch, no wait inside the
+ * kernel): bn->sums are that block's `stats` rows, save_mean / save_invstd (for kd6d_bn_train_bwd of that block) and the
+ * running statistics are written by this launch, and z_out (optional, (rows_in, cin) in `dtype`) receives the
+ * activation the weight gradient of THIS convolution reads.  bn != NULL needs a 1x1 or 3x3 stride-1 'same' convolution. */
+typedef struct kd6d_bn_in {
+  const float* sums;
+  int32_t replicas;
+  int32_t act;
+  float eps;
+  float momentum;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+} kd6d_bn_in;
+int kd6d_conv2d_fwd_block(const kd6d_conv_geom* g, int dtype, const void* x, const kd6d_bn_in* bn, void* z_out,
+                          const void* w, float* y_raw, float* stats, int stats_replicas, void* stream);
+
 /* dx (+)= conv_transpose(dy, w).  wt is the dgrad packing wt[cin][ky][kx][cout]
  * produced by kd6d_pack_dgrad_weights.  accumulate != 0 adds into dx. */
 int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void* dy,
@@ -196,8 +220,8 @@ typedef struct kd6d_levels {
 int kd6d_device_cu_count(void);
 
 /* Kernel-selection options.  The dispatch rules inside the library are measured defaults; the parity tests and the
- * per-layer benches pin one kernel family for a call through this table (process-wide, set between launches by the
- * launching thread).  The product path sets none of them.  Names and values:
+ * per-layer benches pin one kernel family for a call through this table (per context, see kd6d_ctx below; set between
+ * launches by the launching thread).  The product path sets none of them.  Names and values:
  *   conv.halo      -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64,
  *                  11-15 the two-workgroups-per-CU twins (maps <= 32 wide): 128x128 on 4 / 8 waves, 128x64, 64x64, 128x32
  *   conv.halo_pairing  1 | 0 keep the one-workgroup-per-CU halo tiles on maps <= 32 wide
@@ -207,7 +231,30 @@ int kd6d_device_cu_count(void);
  *   wgrad.small    -1 auto | 0 off | 1 the narrow-layer weight-gradient kernel at any size
  *   bn.onepass      1 | 0 two-launch BatchNorm backward     bn.onepass_max  largest x in 16-B granules (65536)
  *   gn.onepass      1 | 0 two-launch GroupNorm backward     sinkhorn.lanes  1 | 0 general path for every point set
+ *   conv.fuse_norm  bit 0: GroupNorm, bit 1: BatchNorm geometries may take kd6d_conv2d_fwd_norm (3 | 0: fusable() = 0)
+ *   sinkhorn.dense_mfma  dense OT, D = 16: 1 gradient-free softmin passes on the fp32 matrix pipe while
+ *                  eps >= 1.5e-4 diameter^2 | 0 never | 2 every gradient-free pass (error studies)
  * Unknown names return KD6D_ERR_ARG. */
+/* Context: the library's mutable state -- the option table, the pair bracket of kd6d_conv2d_pair_begin/_end and the
+ * counter of in-kernel barrier waits that gave up -- lives in a kd6d_ctx.  Every entry point of this header acts on the
+ * CALLING THREAD'S CURRENT context: the one set with kd6d_ctx_make_current(), else the process-wide default context
+ * (what a host that never creates one gets; it cannot be destroyed).  Two models in one process that must not share
+ * kernel-selection state each create a context and make it current around their calls (or use the kd6d_ctx_* forms,
+ * which take the context explicitly; ctx == NULL means "the current one").  Contexts are not thread-safe: one thread
+ * at a time per context.  The RCCL communicator (kd6d_comm) is its own handle and is passed explicitly already. */
+typedef struct kd6d_ctx kd6d_ctx;
+int kd6d_ctx_create(kd6d_ctx** out);               /* options at their defaults, no bracket open, counter 0; needs a device */
+int kd6d_ctx_destroy(kd6d_ctx* ctx);
+int kd6d_ctx_make_current(kd6d_ctx* ctx);          /* NULL: back to the default context */
+kd6d_ctx* kd6d_ctx_current(void);
+int kd6d_ctx_set_option(kd6d_ctx* ctx, const char* name, long long value);
+int kd6d_ctx_get_option(kd6d_ctx* ctx, const char* name, long long* value);
+int kd6d_ctx_reset_options(kd6d_ctx* ctx);
+int kd6d_ctx_barrier_timeouts(kd6d_ctx* ctx);      /* of launches issued under that context */
+int kd6d_ctx_conv2d_pair_begin(kd6d_ctx* ctx);
+int kd6d_ctx_conv2d_pair_end(kd6d_ctx* ctx);
+int kd6d_ctx_conv2d_pair_pending(kd6d_ctx* ctx);
+
 int kd6d_set_option(const char* name, long long value);
 int kd6d_get_option(const char* name, long long* value);
 int kd6d_reset_options(void);

@@ -73,6 +73,18 @@ struct ConvParams {
   float* bn_save_invstd;
   float* bn_running_mean;
   float* bn_running_var;
+  // ---- train-mode BatchNorm + activation of the PREVIOUS block applied while this convolution loads its input
+  // (conv_igemm_kernel<..., XF = true>; kd6d_conv2d_fwd_bn_in): src is that block's fp32 conv output ----
+  const float* xf_sum;         // xf_replicas rows of {sum[C], sumsq[C]} (what the previous launch's epilogue accumulated)
+  const float* xf_gamma;
+  const float* xf_beta;
+  float* xf_save_mean;         // outputs for the backward pass of the previous block (written by workgroup 0)
+  float* xf_save_invstd;
+  float* xf_running_mean;      // updated in place by workgroup 0 (optional)
+  float* xf_running_var;
+  void* xf_z;                  // optional: the activation act(bn(src)) as T, (rows_in, C) -- what the weight gradient reads
+  float xf_eps, xf_inv_rows, xf_momentum, xf_unbias;
+  int xf_replicas, xf_act;
 };
 
 template <typename T> struct Frag;
@@ -232,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
     __syncthreads();
     // fused normalisation: replica rows (hundreds of workgroups adding into one address retire one after the other,
     // ~25 ns each) and RETURNING atomics (visible before this workgroup arrives at the barrier, kd6d_barrier.h)
-    const int rep = p.norm_dst && p.stats_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.stats_replicas) : 0;
+    const int rep = p.stats_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.stats_replicas) : 0;
     for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
       const int which = i / BC, nl = i - which * BC;
       if (n0 + nl < p.N) {

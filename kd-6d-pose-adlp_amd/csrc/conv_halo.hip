@@ -264,7 +264,16 @@ struct PairState {
   int count = 0;
   HaloRecord rec[2];
 };
-thread_local PairState g_pair;
+// the pair bracket belongs to the calling thread's current context (kd6d_ctx)
+PairState& pair_state() {
+  kd6d_ctx* c = kd6d_current_ctx();
+  if (!c->pair) {
+    c->pair = new PairState;
+    c->pair_free = [](void* q) { delete static_cast<PairState*>(q); };
+  }
+  return *static_cast<PairState*>(c->pair);
+}
+#define g_pair (pair_state())
 
 template <int BP, int BC, int WP, int WC, int MODE, int HMAX, bool PDB>
 size_t halo_lds() {
@@ -392,6 +401,21 @@ bool kd6d_detail::dispatch_halo_fwd(const ConvParams& p, const kd6d_conv_geom* g
 bool kd6d_detail::dispatch_halo_dgrad(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
   return dispatch_halo<MODE_DGRAD>(p, g, st);
 }
+
+#undef g_pair
+
+namespace {
+struct CtxScope {           // run an entry point under an explicit context
+  kd6d_ctx* saved;
+  explicit CtxScope(kd6d_ctx* c) : saved(kd6d_ctx_current()) { if (c) kd6d_ctx_make_current(c); }
+  ~CtxScope() { kd6d_ctx_make_current(saved); }
+};
+}  // namespace
+#define g_pair (pair_state())
+
+extern "C" int kd6d_ctx_conv2d_pair_begin(kd6d_ctx* c) { CtxScope s(c); return kd6d_conv2d_pair_begin(); }
+extern "C" int kd6d_ctx_conv2d_pair_end(kd6d_ctx* c) { CtxScope s(c); return kd6d_conv2d_pair_end(); }
+extern "C" int kd6d_ctx_conv2d_pair_pending(kd6d_ctx* c) { CtxScope s(c); return kd6d_conv2d_pair_pending(); }
 
 extern "C" int kd6d_conv2d_pair_begin(void) {
   KD6D_CHECK_ARG(!g_pair.active, "kd6d_conv2d_pair_begin: already inside a pair bracket");

@@ -24,7 +24,13 @@ using namespace kd6d_detail;
 
 namespace {
 
-template <typename T, int BP, int BC, int WP, int WC, int MODE>
+// XF = true (forward only): the gather source is the PREVIOUS ConvBlock's fp32 conv output and its train-mode BatchNorm
+// + activation (backbone/common.py:316-324) is applied while the pixel operand is loaded -- scale / shift per channel
+// from the batch sums that block's epilogue accumulated, the same fma + LeakyReLU as bn_apply_fwd_kernel, one rounding to
+// T -- so the separate normalise launch and its (rows, C) round trip go without any wait inside a kernel.  The
+// activation tensor the weight gradient needs is written on the way (centre tap, channel tile 0: every input pixel
+// exactly once); workgroup 0 publishes save_mean / save_invstd and updates the running statistics.
+template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int EG = Granule<T>::N;
   constexpr int BK = 8 * EG;
@@ -75,6 +81,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   u32x4_t preg[PR], creg[CR];
 
+  // XF: per-channel scale / shift of the previous block's BatchNorm in LDS, behind the two tile buffers
+  float* const xf_tab = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);      // sc[C] | sh[C]
+  if constexpr (XF) {
+    const int R = p.xf_replicas > 1 ? p.xf_replicas : 1;
+    for (int c = tid; c < p.C; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int r = 0; r < R; ++r) {
+        s1 += p.xf_sum[(size_t)(2 * r) * p.C + c];
+        s2 += p.xf_sum[(size_t)(2 * r + 1) * p.C + c];
+      }
+      const float mean = s1 * p.xf_inv_rows;
+      const float var = fmaxf(s2 * p.xf_inv_rows - mean * mean, 0.f);
+      const float is = rsqrtf(var + p.xf_eps);
+      const float sc = p.xf_gamma[c] * is;
+      xf_tab[c] = sc;
+      xf_tab[p.C + c] = __builtin_fmaf(-mean, sc, p.xf_beta[c]);
+      if (blockIdx.x == 0) {
+        if (p.xf_save_mean) p.xf_save_mean[c] = mean;
+        if (p.xf_save_invstd) p.xf_save_invstd[c] = is;
+        if (p.xf_running_mean) p.xf_running_mean[c] = (1.f - p.xf_momentum) * p.xf_running_mean[c] + p.xf_momentum * mean;
+        if (p.xf_running_var) p.xf_running_var[c] = (1.f - p.xf_momentum) * p.xf_running_var[c] + p.xf_momentum * var * p.xf_unbias;
+      }
+    }
+    __syncthreads();
+  }
+  const int center_tap = (p.ks * p.ks) >> 1;
+
   auto issue_loads = [&](int kt) {
     const int kk = kt * BK + gcol * EG;
     const bool kvalid = kk < p.K;
@@ -82,6 +115,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int cc = kk - tap * p.C;
     const int ky = tap / p.ks;
     const int kx = tap - ky * p.ks;
+    float xsc[XF ? EG : 1], xsh[XF ? EG : 1];
+    if constexpr (XF) {
+#pragma unroll
+      for (int e = 0; e < EG; ++e) {
+        xsc[e] = kvalid ? xf_tab[cc + e] : 0.f;
+        xsh[e] = kvalid ? xf_tab[p.C + cc + e] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PR; ++i) {
       const int sh = rhw[i] >> 16, sw = rhw[i] & 0xffff;
@@ -104,7 +145,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (ok) {
         const size_t off = (size_t)(rbase[i] + sy * sw + sx) * (size_t)p.C + (size_t)cc;
-        v = *reinterpret_cast<const u32x4_t*>(src + off);
+        if constexpr (XF) {
+          const float* __restrict__ raw = reinterpret_cast<const float*>(p.src) + off;
+          float f[EG];
+#pragma unroll
+          for (int e4 = 0; e4 < EG; e4 += 4) {
+            const f32x4_t q = *reinterpret_cast<const f32x4_t*>(raw + e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = __builtin_fmaf(q[e], xsc[e4 + e], xsh[e4 + e]);
+              if (p.xf_act == KD6D_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+              else if (p.xf_act == KD6D_ACT_RELU) t = fmaxf(t, 0.f);
+              f[e4 + e] = t;
+            }
+          }
+          v = f32_to_granule<T>(f);
+          if (p.xf_z && tap == center_tap && tile_c == 0)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<T*>(p.xf_z) + off) = v;
+        } else {
+          v = *reinterpret_cast<const u32x4_t*>(src + off);
+        }
       }
       preg[i] = v;
     }
@@ -1162,20 +1222,20 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ w
 }
 
 
-template <typename T, int BP, int BC, int WP, int WC, int MODE>
+template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false>
 void launch_igemm(const ConvParams& p, hipStream_t st) {
   ConvParams q = p;
   q.n_ctiles = (p.N + BC - 1) / BC;
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(q, ptiles, BP, BC);
-  const size_t lds = (size_t)(BP + BC) * 128 * 2;
+  const size_t lds = (size_t)(BP + BC) * 128 * 2 + (XF ? (size_t)2 * p.C * sizeof(float) : 0);
   if (plan_only(ptiles * q.n_ctiles, 256, lds, true)) return;
-  auto kern = conv_igemm_kernel<T, BP, BC, WP, WC, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  auto kern = conv_igemm_kernel<T, BP, BC, WP, WC, MODE, XF>;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_lds = lds;
   }
   hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q);
 }
@@ -1332,23 +1392,23 @@ bool dispatch_glds(const ConvParams& p, hipStream_t st) {
   return true;
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool XF = false>
 void dispatch_igemm(const ConvParams& p, hipStream_t st) {
   const int N = p.N, M = p.M;
   auto nblocks = [&](int bp, int bc) { return ((M + bp - 1) / bp) * ((N + bc - 1) / bc); };
   if (N <= 16) {
-    if (nblocks(256, 16) >= 512) launch_igemm<T, 256, 16, 4, 1, MODE>(p, st);
-    else launch_igemm<T, 64, 16, 4, 1, MODE>(p, st);
+    if (nblocks(256, 16) >= 512) launch_igemm<T, 256, 16, 4, 1, MODE, XF>(p, st);
+    else launch_igemm<T, 64, 16, 4, 1, MODE, XF>(p, st);
   } else if (N <= 32) {
-    if (nblocks(256, 32) >= 512) launch_igemm<T, 256, 32, 4, 1, MODE>(p, st);
-    else launch_igemm<T, 64, 32, 4, 1, MODE>(p, st);
+    if (nblocks(256, 32) >= 512) launch_igemm<T, 256, 32, 4, 1, MODE, XF>(p, st);
+    else launch_igemm<T, 64, 32, 4, 1, MODE, XF>(p, st);
   } else if (N <= 64) {
-    if (nblocks(128, 64) >= 384) launch_igemm<T, 128, 64, 2, 2, MODE>(p, st);
-    else launch_igemm<T, 64, 64, 2, 2, MODE>(p, st);
+    if (nblocks(128, 64) >= 384) launch_igemm<T, 128, 64, 2, 2, MODE, XF>(p, st);
+    else launch_igemm<T, 64, 64, 2, 2, MODE, XF>(p, st);
   } else {
-    if (nblocks(128, 128) >= 384) launch_igemm<T, 128, 128, 2, 2, MODE>(p, st);
-    else if (nblocks(128, 64) >= 384) launch_igemm<T, 128, 64, 2, 2, MODE>(p, st);
-    else launch_igemm<T, 64, 64, 2, 2, MODE>(p, st);
+    if (nblocks(128, 128) >= 384) launch_igemm<T, 128, 128, 2, 2, MODE, XF>(p, st);
+    else if (nblocks(128, 64) >= 384) launch_igemm<T, 128, 64, 2, 2, MODE, XF>(p, st);
+    else launch_igemm<T, 64, 64, 2, 2, MODE, XF>(p, st);
   }
 }
 
@@ -1595,6 +1655,45 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
   return KD6D_OK;
 }
 
+extern "C" int kd6d_conv2d_fwd_block(const kd6d_conv_geom* g, int dtype, const void* x, const kd6d_bn_in* bn, void* z_out,
+                                     const void* w, float* y_raw, float* stats, int stats_replicas, void* stream) {
+  ConvParams p;
+  int rc = fwd_params(g, dtype, "kd6d_conv2d_fwd_block", p);
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && w && y_raw, "kd6d_conv2d_fwd_block: null tensor pointer");
+  KD6D_CHECK_ARG(stats_replicas >= 1 && stats_replicas <= 64, "kd6d_conv2d_fwd_block: stats_replicas=%d", stats_replicas);
+  p.src = x; p.wgt = w; p.dst = y_raw;
+  p.act = KD6D_ACT_NONE; p.out_f32 = 1;
+  if (stats) {
+    rc = set_stats(g, p, stats, 0, "kd6d_conv2d_fwd_block");
+    if (rc) return rc;
+    p.stats_replicas = stats_replicas;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!bn) {
+    KD6D_CHECK_ARG(z_out == nullptr, "kd6d_conv2d_fwd_block: z_out without a BatchNorm to apply");
+    dispatch_fwd(p, g, dtype, nullptr, 0, st);
+  } else {
+    KD6D_CHECK_ARG(bn->sums && bn->gamma && bn->beta && bn->replicas >= 1 && bn->act >= 0 && bn->act <= 2,
+                   "kd6d_conv2d_fwd_block: bad BatchNorm description");
+    KD6D_CHECK_ARG(g->stride == 1 && (g->ksize == 1 || g->ksize == 3) && g->pad == g->ksize / 2,
+                   "kd6d_conv2d_fwd_block: BatchNorm-on-load needs a 1x1 or 3x3 stride-1 'same' convolution");
+    long long rows_in = 0;
+    for (int s = 0; s < g->nseg; ++s) rows_in += (long long)g->batch * g->seg[s].in_h * g->seg[s].in_w;
+    p.xf_sum = bn->sums; p.xf_replicas = bn->replicas; p.xf_gamma = bn->gamma; p.xf_beta = bn->beta;
+    p.xf_eps = bn->eps; p.xf_momentum = bn->momentum; p.xf_act = bn->act;
+    p.xf_inv_rows = 1.0f / (float)rows_in;
+    p.xf_unbias = rows_in > 1 ? (float)rows_in / (float)(rows_in - 1) : 1.0f;
+    p.xf_save_mean = bn->save_mean; p.xf_save_invstd = bn->save_invstd;
+    p.xf_running_mean = bn->running_mean; p.xf_running_var = bn->running_var;
+    p.xf_z = z_out;
+    if (dtype == KD6D_BF16) dispatch_igemm<bf16_t, MODE_FWD, true>(p, st);
+    else dispatch_igemm<float, MODE_FWD, true>(p, st);
+  }
+  KD6D_CHECK_LAUNCH("kd6d_conv2d_fwd_block");
+  return KD6D_OK;
+}
+
 extern "C" int kd6d_conv2d_fwd_norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups) {
   if (!g || (kind != KD6D_NORM_GROUP && kind != KD6D_NORM_BATCH)) return 0;
   ConvParams p;
@@ -1616,7 +1715,7 @@ extern "C" int kd6d_conv2d_fwd_norm(const kd6d_conv_geom* g, int dtype, const vo
     kd6d_set_error("kd6d_conv2d_fwd_norm: this geometry does not take the fused path (kd6d_conv2d_fwd_norm_fusable)");
     return KD6D_ERR_UNSUPPORTED;
   }
-  unsigned int* timeouts = barrier_timeouts_device_ptr();
+  unsigned int* timeouts = kd6d_ctx_timeouts_ptr();
   KD6D_CHECK_ARG(timeouts != nullptr, "kd6d_conv2d_fwd_norm: no barrier-timeout counter");
   p.src = x; p.wgt = w; p.dst = raw_out;
   p.ch_shift = bias; p.act = KD6D_ACT_NONE; p.out_f32 = 1;

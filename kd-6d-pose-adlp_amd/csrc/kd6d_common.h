@@ -51,9 +51,24 @@ enum Kd6dOption {
   KD6D_OPT_SINKHORN_LANES,     // 1 | 0: every set on the general (one softmin after the other) path
   KD6D_OPT_CONV_HALO_PAIRING,  // 1 | 0: maps <= 32 wide keep the double-buffered (one workgroup per CU) halo tiles
   KD6D_OPT_CONV_FUSE_NORM,     // bit 0: GroupNorm, bit 1: BatchNorm geometries may take the fused launch (0: kd6d_conv2d_fwd_norm_fusable reports 0)
+  KD6D_OPT_SINKHORN_DENSE_MFMA,  // dense OT, D = 16: 1 the fp32 matrix-pipe softmin where its cancellation error allows | 0 never | 2 always
   KD6D_OPT_COUNT
 };
-long long kd6d_opt(int id);
+long long kd6d_opt(int id);          // of the calling thread's current context
+
+// ---- context (kd6d_ctx, include/kd6d.h): what used to be process-global state ------------------------------------
+// Options, the pair bracket of conv_halo.hip and the barrier-timeout counter live in a context; every entry point of
+// the library acts on the calling thread's CURRENT context (kd6d_ctx_make_current; none made current: the
+// process-wide default context, which is what the Python host uses).
+struct kd6d_ctx {
+  long long opt[KD6D_OPT_COUNT];
+  void* pair;                    // conv_halo.hip's PairState, created on first use
+  void (*pair_free)(void*);
+  unsigned int* timeouts;        // device word counting barrier waits that gave up
+  bool owns_timeouts;
+};
+kd6d_ctx* kd6d_current_ctx();
+unsigned int* kd6d_ctx_timeouts_ptr();      // device address of the current context's counter
 
 // ---- scalar conversions ---------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -24,37 +24,108 @@ struct OptRow { const char* name; long long def; };
 const OptRow kOptRows[KD6D_OPT_COUNT] = {
     {"conv.halo", -1},  {"conv.smallc", -1},       {"conv.splitk", -1}, {"conv.tile", -1},     {"wgrad.small", -1},
     {"bn.onepass", 1},  {"bn.onepass_max", 65536}, {"gn.onepass", 1},   {"sinkhorn.lanes", 1},
-    {"conv.halo_pairing", 1}, {"conv.fuse_norm", 3},
+    {"conv.halo_pairing", 1}, {"conv.fuse_norm", 3}, {"sinkhorn.dense_mfma", 1},
 };
-long long g_opt[KD6D_OPT_COUNT] = {-1, -1, -1, -1, -1, 1, 65536, 1, 1, 1, 3};
 int opt_index(const char* name) {
   if (!name) return -1;
   for (int i = 0; i < KD6D_OPT_COUNT; ++i)
     if (strcmp(name, kOptRows[i].name) == 0) return i;
   return -1;
 }
+
+void ctx_defaults(kd6d_ctx* c) {
+  for (int i = 0; i < KD6D_OPT_COUNT; ++i) c->opt[i] = kOptRows[i].def;
+  c->pair = nullptr; c->pair_free = nullptr; c->timeouts = nullptr; c->owns_timeouts = false;
+}
+
+kd6d_ctx* default_ctx() {
+  static kd6d_ctx ctx = []() { kd6d_ctx c; ctx_defaults(&c); return c; }();
+  return &ctx;
+}
+thread_local kd6d_ctx* g_current = nullptr;
 }  // namespace
 
-long long kd6d_opt(int id) { return g_opt[id]; }
+namespace kd6d_detail { unsigned int* barrier_timeouts_device_ptr(); }      // norm_ops.hip: the default context's word
 
-extern "C" int kd6d_set_option(const char* name, long long value) {
+kd6d_ctx* kd6d_current_ctx() { return g_current ? g_current : default_ctx(); }
+
+unsigned int* kd6d_ctx_timeouts_ptr() {
+  kd6d_ctx* c = kd6d_current_ctx();
+  if (!c->timeouts) c->timeouts = kd6d_detail::barrier_timeouts_device_ptr();     // default context: the library's symbol
+  return c->timeouts;
+}
+
+long long kd6d_opt(int id) { return kd6d_current_ctx()->opt[id]; }
+
+extern "C" int kd6d_ctx_create(kd6d_ctx** out) {
+  KD6D_CHECK_ARG(out != nullptr, "kd6d_ctx_create: null output");
+  kd6d_ctx* c = new kd6d_ctx;
+  ctx_defaults(c);
+  void* word = nullptr;
+  if (hipMalloc(&word, sizeof(unsigned int)) != hipSuccess || hipMemset(word, 0, sizeof(unsigned int)) != hipSuccess) {
+    if (word) (void)hipFree(word);
+    delete c;
+    kd6d_set_error("kd6d_ctx_create: could not allocate the barrier-timeout counter (no device?)");
+    return KD6D_ERR_LAUNCH;
+  }
+  c->timeouts = reinterpret_cast<unsigned int*>(word);
+  c->owns_timeouts = true;
+  *out = c;
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_ctx_destroy(kd6d_ctx* c) {
+  if (!c) return KD6D_OK;
+  KD6D_CHECK_ARG(c != default_ctx(), "kd6d_ctx_destroy: the default context cannot be destroyed");
+  if (g_current == c) g_current = nullptr;
+  if (c->pair && c->pair_free) c->pair_free(c->pair);
+  if (c->owns_timeouts && c->timeouts) (void)hipFree(c->timeouts);
+  delete c;
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_ctx_make_current(kd6d_ctx* c) {
+  g_current = (c == default_ctx()) ? nullptr : c;
+  return KD6D_OK;
+}
+
+extern "C" kd6d_ctx* kd6d_ctx_current(void) { return kd6d_current_ctx(); }
+
+extern "C" int kd6d_ctx_set_option(kd6d_ctx* c, const char* name, long long value) {
   const int i = opt_index(name);
   KD6D_CHECK_ARG(i >= 0, "kd6d_set_option: unknown option '%s'", name ? name : "(null)");
-  g_opt[i] = value;
+  (c ? c : kd6d_current_ctx())->opt[i] = value;
   return KD6D_OK;
 }
 
-extern "C" int kd6d_get_option(const char* name, long long* value) {
+extern "C" int kd6d_ctx_get_option(kd6d_ctx* c, const char* name, long long* value) {
   const int i = opt_index(name);
   KD6D_CHECK_ARG(i >= 0 && value, "kd6d_get_option: unknown option '%s'", name ? name : "(null)");
-  *value = g_opt[i];
+  *value = (c ? c : kd6d_current_ctx())->opt[i];
   return KD6D_OK;
 }
 
-extern "C" int kd6d_reset_options(void) {
-  for (int i = 0; i < KD6D_OPT_COUNT; ++i) g_opt[i] = kOptRows[i].def;
+extern "C" int kd6d_ctx_reset_options(kd6d_ctx* c) {
+  c = c ? c : kd6d_current_ctx();
+  for (int i = 0; i < KD6D_OPT_COUNT; ++i) c->opt[i] = kOptRows[i].def;
   return KD6D_OK;
 }
+
+extern "C" int kd6d_ctx_barrier_timeouts(kd6d_ctx* c) {
+  kd6d_ctx* saved = g_current;
+  if (c) g_current = (c == default_ctx()) ? nullptr : c;
+  unsigned int* p = kd6d_ctx_timeouts_ptr();
+  g_current = saved;
+  unsigned int v = 0;
+  if (!p || hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)v;
+}
+
+// the context-free forms act on the calling thread's current context
+extern "C" int kd6d_set_option(const char* name, long long value) { return kd6d_ctx_set_option(nullptr, name, value); }
+extern "C" int kd6d_get_option(const char* name, long long* value) { return kd6d_ctx_get_option(nullptr, name, value); }
+extern "C" int kd6d_reset_options(void) { return kd6d_ctx_reset_options(nullptr); }
+extern "C" int kd6d_barrier_timeouts(void) { return kd6d_ctx_barrier_timeouts(nullptr); }
 
 // Number of compute units of the current device (host query, no sync).
 extern "C" int kd6d_device_cu_count(void) {

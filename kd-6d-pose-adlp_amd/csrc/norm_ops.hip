@@ -71,12 +71,12 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
 // In-kernel barriers: kd6d_barrier.h (atomic_add_performed, group_barrier, grid_barrier, the residency argument).  The
 // kernels of this file count their give-ups here; the convolution epilogues add to the same word through its device
 // address (barrier_timeouts_device_ptr).
-__device__ unsigned int g_barrier_timeouts = 0;
-__device__ __forceinline__ void group_barrier(unsigned int* ctr, unsigned need) {
-  kd6d_detail::group_barrier(ctr, need, &g_barrier_timeouts);
+__device__ unsigned int g_barrier_timeouts = 0;      // the default context's counter; other contexts own a word each
+__device__ __forceinline__ void group_barrier(unsigned int* ctr, unsigned need, unsigned int* timeouts) {
+  kd6d_detail::group_barrier(ctr, need, timeouts);
 }
-__device__ __forceinline__ void grid_barrier(unsigned int* ctr, unsigned nblocks) {
-  kd6d_detail::grid_barrier(ctr, blockIdx.x, nblocks, &g_barrier_timeouts);
+__device__ __forceinline__ void grid_barrier(unsigned int* ctr, unsigned nblocks, unsigned int* timeouts) {
+  kd6d_detail::grid_barrier(ctr, blockIdx.x, nblocks, timeouts);
 }
 
 // Row-tiled variant of the ownership rule: thread t owns channel granule t % cgs of row t / cgs
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kThreads, 3) void bn_bwd_onepass_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int per_thread, int C,
     float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat,
-    unsigned int* counter, float* dgamma, float* dbeta, int replicas) {
+    unsigned int* counter, float* dgamma, float* dbeta, int replicas, unsigned int* timeouts) {
   constexpr int EG = Granule<T>::N;
   extern __shared__ float red[];             // 2 * C (block_channel_flush, then the totals)
   const int cgs = C / EG;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kThreads, 3) void bn_bwd_onepass_kernel(
   }
   float* outs[2] = {sum_dy, sum_dy_xhat};
   block_channel_flush<2, EG, true>(acc, C, cg, outs, replicas);
-  grid_barrier(counter, gridDim.x);
+  grid_barrier(counter, gridDim.x, timeouts);
   // only the RAW slice crosses the barrier: without this the compiler also keeps xhat and the masked gradient of
   // the first phase alive (twice the registers, half the resident workgroups)
 #pragma unroll
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
     const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int items, int per_thread, int H, int W,
     int C, float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat,
-    unsigned int* counter, float* dgamma, float* dbeta, int replicas) {
+    unsigned int* counter, float* dgamma, float* dbeta, int replicas, unsigned int* timeouts) {
   constexpr int EG = Granule<T>::N;
   extern __shared__ float red[];
   const int cgs = C / EG;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
   }
   float* outs[2] = {sum_dy, sum_dy_xhat};
   block_channel_flush<2, EG, true>(acc, C, cg, outs, replicas);
-  grid_barrier(counter, gridDim.x);
+  grid_barrier(counter, gridDim.x, timeouts);
   replica_totals(sum_dy, sum_dy_xhat, C, replicas, red);
   float k1[EG], k2[EG];
 #pragma unroll
@@ -727,6 +727,7 @@ struct GnGeom {
   int blk0[KD6D_MAX_SEG];     // first reduction workgroup of the level
   int cps[KD6D_MAX_SEG];      // reduction workgroups (row chunks) per sample
   int chunk_rows;
+  unsigned int* timeouts;     // the launching context's counter of barrier waits that gave up
 };
 
 // reduction workgroup -> (seg, b, first row, row count)
@@ -1030,7 +1031,7 @@ __device__ __forceinline__ void gn_relu_bwd_onepass_body(
   }
   // (the dgamma / dbeta atomics -- every workgroup of the launch on the same C addresses -- wait until the end:
   //  the siblings do not need them and the barrier would otherwise sit behind that queue)
-  group_barrier(counters + seg * gm.batch + b, (unsigned)((hw + gm.chunk_rows - 1) / gm.chunk_rows));
+  group_barrier(counters + seg * gm.batch + b, (unsigned)((hw + gm.chunk_rows - 1) / gm.chunk_rows), gm.timeouts);
   float k1[EG], k2[EG];
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
@@ -1346,6 +1347,7 @@ bool fill_gn(const int32_t* level_hw, int nseg, int batch, int C, int G, GnGeom*
   if (nseg < 1 || nseg > KD6D_MAX_SEG || batch < 1 || G < 1 || G > 64 || C % G) return false;
   gm->nseg = nseg; gm->batch = batch; gm->C = C; gm->G = G;
   gm->chunk_rows = chunk_rows > 0 ? chunk_rows : gn_chunk_rows();
+  gm->timeouts = kd6d_ctx_timeouts_ptr();
   int row = 0, blk = 0;
   for (int s = 0; s < KD6D_MAX_SEG; ++s) {
     gm->row0[s] = row;
@@ -1537,7 +1539,7 @@ extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void
                hipLaunchKernelGGL((bn_bwd_onepass_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads),
                                   (size_t)2 * C * sizeof(float), st, (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, per,
                                   C, inv_rows, mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma,
-                                  dbeta, replicas));
+                                  dbeta, replicas, kd6d_ctx_timeouts_ptr()));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd");
   return KD6D_OK;
 }
@@ -1551,11 +1553,6 @@ unsigned int* kd6d_detail::barrier_timeouts_device_ptr() {
   return ptr;
 }
 
-extern "C" int kd6d_barrier_timeouts(void) {
-  unsigned int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_barrier_timeouts), sizeof(v)) != hipSuccess) return -1;
-  return (int)v;
-}
 
 static int check_pool(int dtype, int B, int H, int W, int C, const char* who, long long* items) {
   int rc = check_channels(dtype, C, who);
@@ -1619,7 +1616,8 @@ extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const
     DISPATCH_TTX(dtype, x_f32,
                  hipLaunchKernelGGL((bn_pool_bwd_onepass_kernel<T_, TX_>), dim3((int)nb1), dim3(kThreads), lds, st,
                                     (const TX_*)x, (const T_*)dy, (T_*)dx, (int)items, per, H, W, C, inv_rows, mean,
-                                    invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma, dbeta, replicas));
+                                    invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma, dbeta, replicas,
+                                    kd6d_ctx_timeouts_ptr()));
     KD6D_CHECK_LAUNCH("kd6d_bn_pool_train_bwd");
     return KD6D_OK;
   }

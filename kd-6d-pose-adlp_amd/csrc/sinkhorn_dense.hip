@@ -29,6 +29,7 @@ constexpr int kTile = 128;        // columns staged per LDS tile (kTile / kSplit
 constexpr float kNegLogD = -100000.f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
+constexpr double kMfmaEpsRel = 1.5e-4;   // eps / diameter^2 from which the matrix-pipe softmin is taken (measured: tests)
 
 struct DenseArgs {
   const float* x; const float* y;          // (N,D), (M,D)
@@ -185,6 +186,156 @@ __global__ __launch_bounds__(kThreadsD) void dense_softmin_kernel(const DenseArg
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same softmin on the matrix pipe (D = 16, no gradient): C_ij / eps = k (|r_i|^2 + |c_j|^2 - 2 r_i.c_j), so in the
+// exp2 domain  v_ij = H_j + (2 k2 r_i).c_j - k2 |r_i|^2  with  H_j = h_j log2e - k2 |c_j|^2.  The row term is constant
+// along j and is added after the logsumexp; the inner products come out of v_mfma_f32_32x32x2_f32 (exact fp32 products,
+// fp32 accumulation, the f32 vector rate but on the OTHER pipe), the accumulators start at H_j, and the VALU is left with
+// the online logsumexp: ~4 lane-ops per pair instead of ~40.  A = 32 columns (from LDS), B = 32 rows (in registers for
+// the whole launch), so a lane ends with 16 columns of ONE row: the running (max, sum) of a row lives in the two lanes
+// l, l + 32 and is merged once at the end.
+// The expansion cancels: its absolute error is ~2^-22 (|r|^2 + |c|^2) whatever the distance, i.e. ~k2 2^-22 S in the
+// exponent.  Points are centred (S = spread^2 instead of |p|^2) and the host takes this kernel only while that stays
+// below the fp32 noise the difference form has anyway (eps >= kMfmaEpsRel * diameter^2; the last, gradient-carrying
+// extrapolation and the small-eps steps keep the difference form above).
+// ---------------------------------------------------------------------------
+constexpr int kMRows = 128;        // rows per workgroup: 4 waves x 32
+constexpr int kMTile = 128;        // columns per LDS tile: 4 blocks of 32
+constexpr int kMPitch = 12;        // floats per column and k-parity half (8 used): 48 B -> conflict-free ds_read_b128
+
+__global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs a, const float* __restrict__ center) {
+  constexpr int D = 16;
+  __shared__ __attribute__((aligned(16))) float ce[2][2][kMTile * kMPitch];   // [buffer][k parity][column][k / 2]
+  __shared__ __attribute__((aligned(16))) float hs[2][kMTile];
+  const int which = blockIdx.y;
+  const bool rows_x = (which == 0 || which == 3);
+  const bool cols_x = (which == 0 || which == 2);
+  const float* R = rows_x ? a.x : a.y;
+  const float* Cc = cols_x ? a.x : a.y;
+  const int nr = rows_x ? a.N : a.M;
+  const int nc = cols_x ? a.N : a.M;
+  const float* lw = cols_x ? a.la : a.lb;
+  const int cpot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_bx(a) : off_ay(a);
+  const int opot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_ay(a) : off_bx(a);
+  if (blockIdx.x * kMRows >= nr) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5;                     // which k of each MFMA k-pair this lane feeds
+  const int row = blockIdx.x * kMRows + wave * 32 + (lane & 31);
+  const bool rok = row < nr;
+  const float inv_eps = 1.f / a.eps;
+  const float k2 = 0.5f * inv_eps * kLog2e;
+  // B operand: (2 k2)(r - centre), k = 2 kk + half; and the row term -k2 |r - centre|^2
+  float b[8];
+  float rr = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int k = 2 * kk + half;
+    const float v = rok ? R[(size_t)row * D + k] - center[k] : 0.f;
+    rr += v * v;
+    b[kk] = 2.f * k2 * v;
+  }
+  rr += __shfl_xor(rr, 32, 64);
+
+  auto stage = [&](int buf, int c0) {
+    // 4 threads per column: a float4 of coordinates each -> even / odd k halves; |c|^2 over the quad; H_j
+    for (int i = tid; i < kMTile * 4; i += 256) {
+      const int c = i >> 2, q = i & 3;
+      f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+      const bool ok = c0 + c < nc;
+      if (ok) {
+        v = *reinterpret_cast<const f32x4_t*>(Cc + (size_t)(c0 + c) * D + 4 * q);
+        const f32x4_t ct = *reinterpret_cast<const f32x4_t*>(center + 4 * q);
+        v -= ct;
+      }
+      *reinterpret_cast<f32x2_t*>(&ce[buf][0][c * kMPitch + 2 * q]) = f32x2_t{v[0], v[2]};
+      *reinterpret_cast<f32x2_t*>(&ce[buf][1][c * kMPitch + 2 * q]) = f32x2_t{v[1], v[3]};
+      float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      n2 += __shfl_xor(n2, 1, 64);
+      n2 += __shfl_xor(n2, 2, 64);
+      if (q == 0) {
+        float h = -INFINITY;
+        if (ok) {
+          h = lw[c0 + c];
+          if (a.mode != 0) h += a.pot_old[cpot + c0 + c] * inv_eps;
+          h = h * kLog2e - k2 * n2;
+        }
+        hs[buf][c] = h;
+      }
+    }
+  };
+
+  float m = -1e30f, s = 0.f;
+  const int ntiles = (nc + kMTile - 1) / kMTile;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * kMTile);
+    const float* cA = &ce[buf][half][0];
+#pragma unroll
+    for (int blk = 0; blk < kMTile / 32; ++blk) {
+      typedef float f32x16_t __attribute__((ext_vector_type(16)));
+      f32x16_t acc;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(&hs[buf][blk * 32 + 4 * half + 8 * u]);
+        acc[4 * u + 0] = h4[0]; acc[4 * u + 1] = h4[1]; acc[4 * u + 2] = h4[2]; acc[4 * u + 3] = h4[3];
+      }
+      const float* col = cA + (blk * 32 + (lane & 31)) * kMPitch;
+      const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(col);
+      const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(col + 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], b[3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b[4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b[5], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], b[6], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], b[7], acc, 0, 0, 0);
+      // online logsumexp over this lane's 16 columns of its row (padding columns are -inf)
+      float bm = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+      for (int u = 1; u < 4; ++u) bm = fmaxf(bm, fmaxf(fmaxf(acc[4 * u], acc[4 * u + 1]), fmaxf(acc[4 * u + 2], acc[4 * u + 3])));
+      const float mn = fmaxf(m, bm);
+      float add = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) add += __builtin_amdgcn_exp2f(acc[u] - mn);
+      s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+      m = mn;
+    }
+    __syncthreads();
+  }
+  // the two lanes of a row
+  {
+    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
+    const float mn = fmaxf(m, m2);
+    s = s * __builtin_amdgcn_exp2f(m - mn) + s2 * __builtin_amdgcn_exp2f(m2 - mn);
+    m = mn;
+  }
+  if (half != 0 || !rok) return;
+  const float lse = (m + __builtin_amdgcn_logf(s) - k2 * rr) * kLn2;
+  const float val = -a.lam * a.eps * lse;
+  if (a.mode == 1) a.pot_new[opot + row] = 0.5f * (a.pot_old[opot + row] + val);
+  else a.pot_new[opot + row] = val;
+}
+
+// per-dimension mean of both point sets (D <= 16): the centre the MFMA softmin subtracts
+__global__ __launch_bounds__(256) void dense_center_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
+                                                           int M, int D, float* __restrict__ center) {
+  __shared__ float part[256];
+  const int d = threadIdx.x % D;
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < (long long)N * D; i += 256) acc += x[i];
+  for (long long i = threadIdx.x; i < (long long)M * D; i += 256) acc += y[i];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < D) {
+    float t = 0.f;
+    for (int j = d; j < 256; j += D) t += part[j];
+    center[d] = t / (float)(N + M);
+  }
+}
+
 // log weights (with geomloss' -1e5 for non-positive weights)
 __global__ void dense_logw_kernel(const float* __restrict__ w, float* __restrict__ lw, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -272,6 +423,9 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   float* potB = potA + 2 * (size_t)(N + M);
   float* gxx = potB + 2 * (size_t)(N + M);
   float* gxy = gxx + (size_t)N * D;
+  float* center = gxy + (size_t)N * D;            // 16 floats (the workspace's 64-float tail)
+  const bool use_mfma = D == 16 && kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) != 0;
+  if (use_mfma) hipLaunchKernelGGL(dense_center_kernel, dim3(1), dim3(256), 0, st, x, y, N, M, D, center);
   hipLaunchKernelGGL(dense_logw_kernel, dim3((N + 255) / 256), dim3(256), 0, st, alpha, la, N);
   hipLaunchKernelGGL(dense_logw_kernel, dim3((M + 255) / 256), dim3(256), 0, st, beta, lb, M);
   // epsilon schedule in double, like the reference's python floats (geomloss epsilon_schedule, p = 2)
@@ -294,10 +448,17 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   a.x = x; a.y = y; a.la = la; a.lb = lb; a.N = N; a.M = M; a.grad_xx = gxx; a.grad_xy = gxy;
   float* cur = potA;
   float* nxt = potB;
+  // the matrix-pipe kernel while the cancellation of its |r|^2 + |c|^2 - 2 r.c form stays below ~1e-4 in the exponent
+  // (header of dense_softmin_mfma_kernel): eps >= kMfmaEpsRel * diameter^2; option sinkhorn.dense_mfma: 0 = never,
+  // 1 = by that rule, 2 = every gradient-free pass (tests: how wrong it gets)
+  const double mfma_eps_min = kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) == 2 ? 0.0 : kMfmaEpsRel * diameter * diameter;
+  const dim3 grid_m((nmax + kMRows - 1) / kMRows, 4);
   auto launch = [&](int mode, double eps, bool grad) {
     a.pot_old = cur; a.pot_new = nxt; a.mode = mode; a.eps = (float)eps;
     a.lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
-    if (grad) hipLaunchKernelGGL((dense_softmin_kernel<D, true>), grid, dim3(kThreadsD), 0, st, a);
+    if (!grad && use_mfma && eps >= mfma_eps_min) {
+      if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, (const float*)center);
+    } else if (grad) hipLaunchKernelGGL((dense_softmin_kernel<D, true>), grid, dim3(kThreadsD), 0, st, a);
     else hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
     float* t = cur; cur = nxt; nxt = t;
   };

@@ -52,6 +52,12 @@ class ConvNorm(ctypes.Structure):
                     "gamma", "beta", "y", "stats", "counters", "running_mean", "running_var", "save_mean", "save_invstd")]
 
 
+class BnIn(ctypes.Structure):
+    _fields_ = [("sums", ctypes.c_void_p), ("replicas", ctypes.c_int32), ("act", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("momentum", ctypes.c_float)] + [(n, ctypes.c_void_p) for n in (
+                    "gamma", "beta", "running_mean", "running_var", "save_mean", "save_invstd")]
+
+
 MAX_GT = 4
 MAX_ZERO = 8
 
@@ -81,9 +87,21 @@ SIGNATURES = {
     "kd6d_set_option": [ctypes.c_char_p, ctypes.c_longlong],
     "kd6d_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)],
     "kd6d_reset_options": [],
+    "kd6d_ctx_create": [ctypes.POINTER(_P)],
+    "kd6d_ctx_destroy": [_P],
+    "kd6d_ctx_current": [],
+    "kd6d_ctx_make_current": [_P],
+    "kd6d_ctx_set_option": [_P, ctypes.c_char_p, ctypes.c_longlong],
+    "kd6d_ctx_get_option": [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)],
+    "kd6d_ctx_reset_options": [_P],
+    "kd6d_ctx_barrier_timeouts": [_P],
+    "kd6d_ctx_conv2d_pair_begin": [_P],
+    "kd6d_ctx_conv2d_pair_end": [_P],
+    "kd6d_ctx_conv2d_pair_pending": [_P],
     "kd6d_zero_regions": [ctypes.POINTER(ZeroList), _P, _I, _P],
     "kd6d_uniform_keys": [_P, _I64, _P, ctypes.c_uint64, _P],
     "kd6d_conv2d_fwd": [_G, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I64, _P],
+    "kd6d_conv2d_fwd_block": [_G, _I, _P, ctypes.POINTER(BnIn), _P, _P, _P, _P, _I, _P],
     "kd6d_conv2d_fwd_norm_fusable": [_G, _I, _I, _I],
     "kd6d_conv2d_fwd_norm": [_G, _I, _P, _P, _P, _P, ctypes.POINTER(ConvNorm), _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
@@ -143,7 +161,7 @@ SIGNATURES = {
     "kd6d_comm_broadcast": [_P, _P, _I64, _I, _P],
     "kd6d_comm_destroy": [_P],
 }
-_RESTYPE = {"kd6d_last_error": ctypes.c_char_p}
+_RESTYPE = {"kd6d_last_error": ctypes.c_char_p, "kd6d_ctx_current": ctypes.c_void_p}
 
 
 class Kd6dError(RuntimeError):
@@ -161,7 +179,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name.endswith(("_workspace_floats", "_group_plan")) else ctypes.c_int
+        fn.restype = _RESTYPE.get(name, ctypes.c_int64 if name.endswith(("_workspace_floats", "_group_plan")) else ctypes.c_int)
     if lib.kd6d_abi_version() != ABI_VERSION:
         raise ImportError("libkd6d.so ABI version %d != expected %d" % (lib.kd6d_abi_version(), ABI_VERSION))
     return lib

@@ -270,45 +270,74 @@ class ConvBlock:
         y, g = self.conv.fwd(x, batch, levels, scale=sc, shift=sh, act=ACT_LEAKY, residual=residual)
         return y, g.levels_out
 
-    def fwd_train(self, x, batch, levels, tape, pool=False):
+    def fwd_train(self, x, batch, levels, tape, pool=False, pending=None, defer=False):
         """pool=True: the block is followed by MaxPool2d(2,2) (darknet.py:94-97); normalisation, activation and
-        pooling run as one kernel and only the pooled tensor is stored (csrc/norm_ops.hip, bn_pool_*)."""
+        pooling run as one kernel and only the pooled tensor is stored (csrc/norm_ops.hip, bn_pool_*).
+        defer=True: this block's BatchNorm + LeakyReLU is NOT launched here -- the next block of the stage applies it
+        while it loads its input (kd6d_conv2d_fwd_block); returns (None, levels, pending record for that block).
+        pending: the record of the previous block when ITS normalisation was deferred to this convolution (x is None)."""
         net, st = self.net, self.net.store
         # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
         c = self.conv.cout_p
         geom = self.conv.geom(batch, levels)
         s = net.scratch(self.name, (4 + 2 * self.bwd_replicas(geom.rows_out)) * c + ops.BARRIER_WORDS)   # + the backward's barrier words
         ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
-        # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
-        # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
-        if not pool and net.fuse_norm_on() and self.conv.norm_fusable(batch, levels, ops.NORM_BATCH):
-            # conv -> batch statistics -> normalise + LeakyReLU as ONE launch (grid barrier in the epilogue): the
-            # statistics / apply launches and the re-read of the fp32 tensor go
+        if pending is not None or defer:
             raw = net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32)
-            z = net.buf(self.name + ".z", raw.shape, net.dtype)
-            _, g = self.conv.fwd_norm(x, batch, levels, z, ops.NORM_BATCH, st.storage(self.bn.gamma), st.storage(self.bn.beta),
-                                      ACT_LEAKY, raw_out=raw, eps=1e-5, momentum=0.1, running_mean=st.storage(self.bn.rm),
-                                      running_var=st.storage(self.bn.rv), save_mean=mean, save_invstd=invstd)
-            tape.append((self, x, raw, batch, tuple(levels), None))
-            return z, g.levels_out
-        fused = geom.rows_out <= self.FUSE_STATS_MAX_ROWS
-        raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
-                               out=net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32),
-                               stats=s[0:2 * c] if fused else None, stats_groups=0)
-        if not fused:
-            ops.colstats(raw, ssum, ssq)
+            bn_in = z_in = None
+            if pending is not None:
+                prev, raw_prev, sums_prev, mean_prev, invstd_prev = pending
+                pst = prev.bn
+                bn_in = dict(sums=sums_prev, replicas=ops.BN_REPLICAS, gamma=st.storage(pst.gamma), beta=st.storage(pst.beta),
+                             act=ACT_LEAKY, eps=1e-5, momentum=0.1, running_mean=st.storage(pst.rm),
+                             running_var=st.storage(pst.rv), save_mean=mean_prev, save_invstd=invstd_prev)
+                z_in = net.buf(prev.name + ".z", raw_prev.shape, net.dtype)     # written by this launch: what wgrad reads
+                x = raw_prev
+            if defer:          # the consumer adds the replica rows
+                stats, reps = net.scratch(self.name + ".sums", ops.BN_REPLICAS * 2 * c), ops.BN_REPLICAS
+            else:              # bn_train_fwd / bn_pool_train_fwd below read plain {sum, sumsq}
+                stats, reps = s[0:2 * c], 1
+            fused = defer or geom.rows_out <= self.FUSE_STATS_MAX_ROWS
+            ops.conv2d_fwd_block(geom, x, self.conv.weight(), raw, stats=stats if fused else None, stats_replicas=reps,
+                                 bn_in=bn_in, z_out=z_in, flops=self.conv.flops(geom))
+            g = geom
+            x_saved = z_in if pending is not None else x
+            if defer:
+                tape.append((self, x_saved, raw, batch, tuple(levels), None))
+                return None, g.levels_out, (self, raw, stats, mean, invstd)
+            if not fused:
+                ops.colstats(raw, ssum, ssq)
+            x = x_saved
+        else:
+            if not pool and net.fuse_norm_on() and self.conv.norm_fusable(batch, levels, ops.NORM_BATCH):
+                # conv -> batch statistics -> normalise + LeakyReLU as ONE launch (grid barrier in the epilogue)
+                raw = net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32)
+                z = net.buf(self.name + ".z", raw.shape, net.dtype)
+                _, g = self.conv.fwd_norm(x, batch, levels, z, ops.NORM_BATCH, st.storage(self.bn.gamma), st.storage(self.bn.beta),
+                                          ACT_LEAKY, raw_out=raw, eps=1e-5, momentum=0.1, running_mean=st.storage(self.bn.rm),
+                                          running_var=st.storage(self.bn.rv), save_mean=mean, save_invstd=invstd)
+                tape.append((self, x, raw, batch, tuple(levels), None))
+                return z, g.levels_out, None
+            # batch statistics come out of the conv epilogue; for the long, narrow first layers (hundreds of
+            # workgroups would add into the same 8..64 addresses) a separate reduction pass is cheaper
+            fused = geom.rows_out <= self.FUSE_STATS_MAX_ROWS
+            raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
+                                   out=net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32),
+                                   stats=s[0:2 * c] if fused else None, stats_groups=0)
+            if not fused:
+                ops.colstats(raw, ssum, ssq)
         if pool:
             (h, w), = g.levels_out
             z = net.buf(self.name + ".zpool", (batch * (h // 2) * (w // 2), c), net.dtype)
             ops.bn_pool_train_fwd(raw, z, batch, h, w, ssum, ssq, st.storage(self.bn.gamma), st.storage(self.bn.beta),
                                   1e-5, 0.1, st.storage(self.bn.rm), st.storage(self.bn.rv), mean, invstd, ACT_LEAKY)
             tape.append((self, x, raw, batch, tuple(levels), (h, w)))
-            return z, [(h // 2, w // 2)]
+            return z, [(h // 2, w // 2)], None
         z = net.buf(self.name + ".z", raw.shape, net.dtype)
         ops.bn_train_fwd(raw, z, ssum, ssq, st.storage(self.bn.gamma), st.storage(self.bn.beta), 1e-5, 0.1,
                          st.storage(self.bn.rm), st.storage(self.bn.rv), mean, invstd, ACT_LEAKY)
         tape.append((self, x, raw, batch, tuple(levels), None))
-        return z, g.levels_out
+        return z, g.levels_out, None
 
     def bwd(self, rec, dz, need_dx=True, dx=None, accumulate=False):
         _, x, raw, batch, levels, pooled = rec
@@ -411,6 +440,10 @@ class PoseNet:
         # them: student towers fused -3 %, student BatchNorm blocks fused -1.2 % (interleaved runs on one box,
         # profiles/README.md round 3); a kernel boundary is the cheaper barrier when two streams share the device.
         self.fuse_norm = None
+        # inside a stage of the student's backbone a block's BatchNorm + LeakyReLU is applied by the NEXT block's
+        # convolution while it loads its input (kd6d_conv2d_fwd_block): 10 of the 15 normalise launches (and the 3
+        # separate statistics passes of stage 3) leave the forward chain, without any wait inside a kernel
+        self.bn_on_load = True
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
         self.pair_towers = 1
         self._side_rr = 0
@@ -613,12 +646,12 @@ class PoseNet:
 
     # ---- forward ---------------------------------------------------------------------------
     def _backbone53(self, x, B, lv):
-        x, lv = self.init_block.fwd_eval(x, B, lv) if not self.training else self.init_block.fwd_train(x, B, lv, self.tape)
+        x, lv = self.init_block.fwd_eval(x, B, lv) if not self.training else self.init_block.fwd_train(x, B, lv, self.tape)[:2]
         feats = []
         for units in self.stages:
             for u in units:
                 if u[0] == "down":
-                    x, lv = u[1].fwd_eval(x, B, lv) if not self.training else u[1].fwd_train(x, B, lv, self.tape)
+                    x, lv = u[1].fwd_eval(x, B, lv) if not self.training else u[1].fwd_train(x, B, lv, self.tape)[:2]
                 else:
                     if self.training:
                         raise NotImplementedError("darknet53 is only run as the frozen teacher (eval mode) "
@@ -633,14 +666,20 @@ class PoseNet:
         n = len(self.stages)
         for i, units in enumerate(self.stages):
             if self.training and self.fuse_pool:
+                pending = None
                 for j, u in enumerate(units):
-                    x, lv = u.fwd_train(x, B, lv, self.tape, pool=(i != n - 1 and j == len(units) - 1))
+                    last = j == len(units) - 1
+                    # inside a stage the next block applies this block's BatchNorm + LeakyReLU while loading its input
+                    # (one launch per block instead of conv [+ statistics] + normalise): stages 3-5; the first two
+                    # stages are single blocks
+                    x, lv, pending = u.fwd_train(x, B, lv, self.tape, pool=(i != n - 1 and last), pending=pending,
+                                                 defer=self.bn_on_load and not last)
                 if i != n - 1:
                     self.tape.append(("pooled", i))
                 feats.append((x, lv))
                 continue
             for u in units:
-                x, lv = u.fwd_train(x, B, lv, self.tape) if self.training else u.fwd_eval(x, B, lv)
+                x, lv = u.fwd_train(x, B, lv, self.tape)[:2] if self.training else u.fwd_eval(x, B, lv)
             if i != n - 1:
                 (h, w) = lv[0]
                 y = self.buf("pool%d" % i, (B * (h // 2) * (w // 2), x.shape[1]))

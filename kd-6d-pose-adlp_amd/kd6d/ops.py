@@ -168,6 +168,37 @@ def conv2d_fwd_norm(geom, x, w, y, kind, gamma, beta, stats, counters, act, raw_
     return y
 
 
+BN_REPLICAS = _lib.BN_FUSED_REPLICAS
+
+
+def conv2d_fwd_block(geom, x, w, y_raw, stats=None, stats_replicas=1, bn_in=None, z_out=None, flops=0):
+    """kd6d_conv2d_fwd_block: the convolution of a train-mode ConvBlock -> fp32 y_raw + its batch sums (stats:
+    stats_replicas rows of {sum, sumsq}, pre-zeroed).  bn_in: dict(sums, replicas, gamma, beta, act, eps, momentum,
+    running_mean, running_var, save_mean, save_invstd) -- then x is the PREVIOUS block's fp32 conv output, normalised and
+    activated while loaded, and z_out receives that activation (what this layer's weight gradient reads)."""
+    assert y_raw.shape == (geom.rows_out, geom.cout) and y_raw.dtype == torch.float32
+    assert stats is None or (stats.dtype == torch.float32 and stats.numel() >= stats_replicas * 2 * geom.cout)
+    bn = None
+    if bn_in is not None:
+        assert x.shape == (geom.rows_in, geom.cin) and x.dtype == torch.float32
+        assert z_out is None or (z_out.shape == x.shape and z_out.dtype == w.dtype)
+        bn = _lib.BnIn()
+        bn.replicas, bn.act = int(bn_in["replicas"]), int(bn_in["act"])
+        bn.eps, bn.momentum = float(bn_in.get("eps", 1e-5)), float(bn_in.get("momentum", 0.1))
+        assert bn_in["sums"].numel() >= bn.replicas * 2 * geom.cin
+        for name in ("sums", "gamma", "beta", "running_mean", "running_var", "save_mean", "save_invstd"):
+            t = bn_in.get(name)
+            assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32)
+            setattr(bn, name, t.data_ptr() if t is not None else None)
+    else:
+        assert x.shape == (geom.rows_in, geom.cin) and x.dtype == w.dtype and z_out is None
+    with _Timed("conv_fwd", flops, geom):
+        check(lib.kd6d_conv2d_fwd_block(geom.ref, dt_code(w.dtype), _ptr(x), ctypes.byref(bn) if bn is not None else None,
+                                        _ptr(z_out), _ptr(w), _ptr(y_raw), _ptr(stats), int(stats_replicas), _stream()),
+              "kd6d_conv2d_fwd_block")
+    return y_raw
+
+
 def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     assert dy.shape == (geom.rows_out, geom.cout), (dy.shape, geom.rows_out, geom.cout)
     assert wt.dtype == dy.dtype and wt.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin

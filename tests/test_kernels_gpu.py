@@ -1220,3 +1220,149 @@ def test_conv_fwd_norm_under_repetition(gpu_device):
     torch.cuda.synchronize()
     assert ops.lib.kd6d_barrier_timeouts() == 0
     assert bad == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # (B, C0, C1, k1, C2, k2, (H, W)): block A = conv(C0 -> C1, k1), block B = conv(C1 -> C2, k2): the in-stage
+    # transitions of darknet_tiny_h / darknet_tiny stages 3-5 and odd sizes
+    (16, 16, 8, 1, 64, 3, (64, 64)), (16, 8, 64, 3, 8, 1, (64, 64)), (16, 64, 16, 1, 128, 3, (32, 32)),
+    (16, 16, 128, 3, 16, 1, (32, 32)), (16, 128, 32, 1, 256, 3, (16, 16)), (16, 32, 256, 3, 64, 1, (16, 16)),
+    (4, 32, 256, 3, 32, 1, (15, 20)), (3, 64, 512, 3, 64, 1, (7, 9)),
+])
+def test_conv_block_bn_on_load(gpu_device, dtype, case):
+    """kd6d_conv2d_fwd_block: block A's train-mode BatchNorm + LeakyReLU (backbone/common.py:316-324) applied by block
+    B's convolution while it loads A's fp32 conv output.  Against the separate launches (kd6d_bn_train_fwd on the same
+    batch sums, then kd6d_conv2d_fwd): the activation B writes on the way must be what bn_train_fwd stores, B's conv
+    output and batch sums what the convolution of that tensor gives, and A's save_mean / save_invstd / running statistics
+    must be the ones the separate launch leaves."""
+    ops = _ops()
+    dev = gpu_device
+    B, C0, C1, k1, C2, k2, (H, W) = case
+    if dtype == torch.float32 and B * H * W > 20000:
+        pytest.skip("fp32 mode: covered by the smaller cases")
+    gen = torch.Generator().manual_seed(C0 + 3 * C1 + 7 * C2)
+    R = ops.BN_REPLICAS
+    ga = ops.Geom(B, C0, C1, k1, 1, k1 // 2, [(H, W)])
+    gb = ops.Geom(B, C1, C2, k2, 1, k2 // 2, [(H, W)])
+    x = pack_levels([round_to(torch.randn(B, C0, H, W, generator=gen), dtype)], dtype).to(dev)
+    wa = w_to_krsc(round_to(torch.randn(C1, C0, k1, k1, generator=gen) / (C0 * k1 * k1) ** 0.5, dtype), dtype).to(dev)
+    wb = w_to_krsc(round_to(torch.randn(C2, C1, k2, k2, generator=gen) / (C1 * k2 * k2) ** 0.5, dtype), dtype).to(dev)
+    gamma = (torch.rand(C1, generator=gen) + 0.5).to(dev)
+    beta = (torch.randn(C1, generator=gen) * 0.2).to(dev)
+    rows = ga.rows_out
+    raw_a = torch.empty(rows, C1, device=dev)
+    sums_a = torch.zeros(R, 2, C1, device=dev)
+    ops.conv2d_fwd_block(ga, x, wa, raw_a, stats=sums_a, stats_replicas=R)
+    torch.cuda.synchronize()
+    ref_sum = raw_a.double().sum(0).cpu(); ref_sq = (raw_a.double() ** 2).sum(0).cpu()
+    tot = sums_a.double().sum(0).cpu()
+    torch.testing.assert_close(tot[0], ref_sum, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(tot[1], ref_sq, rtol=1e-4, atol=1e-2)
+    # separate launches on the summed replica rows
+    plain = sums_a.sum(0).contiguous()
+    rm1, rv1 = torch.zeros(C1, device=dev), torch.ones(C1, device=dev)
+    m1, is1 = torch.empty(C1, device=dev), torch.empty(C1, device=dev)
+    z_ref = torch.empty(rows, C1, dtype=dtype, device=dev)
+    ops.bn_train_fwd(raw_a, z_ref, plain[0], plain[1], gamma, beta, 1e-5, 0.1, rm1, rv1, m1, is1, ops.ACT_LEAKY)
+    sums_ref = torch.zeros(2 * C2, device=dev)
+    raw_ref = ops.conv2d_fwd(gb, z_ref, wb, out_f32=True, stats=sums_ref, stats_groups=0)
+    # the one launch
+    rm2, rv2 = torch.zeros(C1, device=dev), torch.ones(C1, device=dev)
+    m2, is2 = torch.empty(C1, device=dev), torch.empty(C1, device=dev)
+    z = torch.full((rows, C1), 7.0, dtype=dtype, device=dev)
+    raw_b = torch.empty(gb.rows_out, C2, device=dev)
+    sums_b = torch.zeros(R, 2, C2, device=dev)
+    ops.conv2d_fwd_block(gb, raw_a, wb, raw_b, stats=sums_b, stats_replicas=R, z_out=z,
+                         bn_in=dict(sums=sums_a, replicas=R, gamma=gamma, beta=beta, act=ops.ACT_LEAKY, eps=1e-5,
+                                    momentum=0.1, running_mean=rm2, running_var=rv2, save_mean=m2, save_invstd=is2))
+    torch.cuda.synchronize()
+    for a, b_ in ((m2, m1), (is2, is1), (rm2, rm1), (rv2, rv1)):
+        torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6)
+    d = (z.float() - z_ref.float()).abs()
+    ulp = z_ref.float().abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 1e-5) + 1e-6
+    assert bool((d <= ulp).all()), float(d.max())               # same arithmetic; the eight rows are added in another order
+    assert float((d > 0).float().mean()) < 1e-2
+    torch.testing.assert_close(raw_b, raw_ref, rtol=2e-3, atol=2e-3)       # a few inputs one rounding step apart
+    torch.testing.assert_close(sums_b.sum(0).reshape(-1), sums_ref, rtol=1e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("blur", [0.05, 0.001])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sinkhorn_dense_matrix_pipe_softmin(gpu_device, blur, mode):
+    """D = 16 (BASELINE config 5's code dimension): the gradient-free softmin passes on the fp32 matrix pipe
+    (dense_softmin_mfma_kernel: r.c from v_mfma_f32_32x32x2_f32, |r|^2 + |c|^2 - 2 r.c form on centred points, taken
+    while eps >= 1.5e-4 diameter^2) against the fp64 oracle at the same tolerances as the difference-form kernel
+    (option sinkhorn.dense_mfma = 0), ragged sizes included."""
+    ops = _ops()
+    from oracle.sinkhorn_ref import sinkhorn_divergence
+    _option("sinkhorn.dense_mfma", mode)
+    N, M, D, reach = 900, 777, 16, 0.5
+    x, a, y, b = _dense_problem(N, M, D, 11, reach)
+    S_r, gx_r, ga_r = sinkhorn_divergence(a[None].astype(np.float64), x[None].astype(np.float64),
+                                          b[None].astype(np.float64), y[None].astype(np.float64), blur=blur,
+                                          scaling=0.5, reach=reach, with_grad=True)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    loss, gx, ga = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach)
+    torch.cuda.synchronize()
+    err = abs(float(loss) - float(S_r[0])) / abs(float(S_r[0]))
+    egx = float(np.abs(gx.cpu().numpy() - gx_r[0]).max() / np.abs(gx_r).max())
+    ega = float(np.abs(ga.cpu().numpy() - ga_r[0]).max() / np.abs(ga_r).max())
+    print("[dense OT D=16 blur %g mfma=%d] loss rel err %.2e, grad_x %.2e, grad_alpha %.2e of scale" % (blur, mode, err, egx, ega))
+    np.testing.assert_allclose(loss.cpu().numpy(), S_r, rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_r[0], rtol=5e-3, atol=5e-3 * np.abs(gx_r).max())
+    np.testing.assert_allclose(ga.cpu().numpy(), ga_r[0], rtol=5e-3, atol=5e-3 * np.abs(ga_r).max())
+
+
+def test_context_isolates_options_pair_bracket_and_timeouts(gpu_device):
+    """kd6d_ctx (include/kd6d.h): options, the pair bracket and the barrier-timeout counter belong to a context; entry
+    points act on the calling thread's current one.  A second context must not see the first one's options or open
+    bracket, a launch issued under it counts its barrier give-ups in its own word, and the default context is what a
+    host that never creates one gets."""
+    import ctypes
+    ops = _ops()
+    lib = ops.lib
+    dev = gpu_device
+    h = ctypes.c_void_p()
+    ops.check(lib.kd6d_ctx_create(ctypes.byref(h)), "kd6d_ctx_create")
+    default = lib.kd6d_ctx_current()
+    try:
+        assert ops.get_option("conv.halo") == -1
+        ops.check(lib.kd6d_ctx_set_option(h, b"conv.halo", 0))
+        assert ops.get_option("conv.halo") == -1                       # the current (default) context is untouched
+        v = ctypes.c_longlong(7)
+        ops.check(lib.kd6d_ctx_get_option(h, b"conv.halo", ctypes.byref(v)))
+        assert v.value == 0
+        ops.check(lib.kd6d_conv2d_pair_begin())                        # bracket open in the default context ...
+        assert lib.kd6d_ctx_conv2d_pair_pending(h) == 0
+        ops.check(lib.kd6d_ctx_conv2d_pair_begin(h))                   # ... does not block one in the other
+        ops.check(lib.kd6d_ctx_conv2d_pair_end(h))
+        ops.check(lib.kd6d_conv2d_pair_end())
+        # a convolution under the new context takes ITS options (halo kernel off -> the generic kernels), same numbers
+        B, C, levels = 2, 64, [(16, 16)]
+        gen = torch.Generator().manual_seed(5)
+        geom = ops.Geom(B, C, C, 3, 1, 1, levels)
+        x = torch.randn(geom.rows_in, C, generator=gen).to(torch.bfloat16).to(dev)
+        w = (torch.randn(C * 9 * C, generator=gen) / 24.0).to(torch.bfloat16).to(dev)
+        y0 = ops.conv2d_fwd(geom, x, w, out_f32=True)
+        ops.check(lib.kd6d_ctx_make_current(h))
+        assert ops.get_option("conv.halo") == 0 and lib.kd6d_ctx_current() == h.value
+        y1 = ops.conv2d_fwd(geom, x, w, out_f32=True)
+        # a barrier kernel under the new context: its counter is its own word
+        gg = ops.Geom(B, 128, 128, 3, 1, 1, [(8, 8), (4, 4)])
+        xg = torch.randn(gg.rows_in, 128, generator=gen).to(torch.bfloat16).to(dev)
+        wg = (torch.randn(128 * 9 * 128, generator=gen) / 34.0).to(torch.bfloat16).to(dev)
+        yg = torch.empty(gg.rows_out, 128, dtype=torch.bfloat16, device=dev)
+        st = torch.zeros(ops.conv_norm_stats_floats(gg, ops.NORM_GROUP, 32), device=dev)
+        ct = torch.zeros(ops.conv_norm_counter_words(gg, ops.NORM_GROUP), dtype=torch.int32, device=dev)
+        ops.conv2d_fwd_norm(gg, xg, wg, yg, ops.NORM_GROUP, torch.ones(128, device=dev), torch.zeros(128, device=dev), st, ct,
+                            ops.ACT_RELU, groups=32)
+        torch.cuda.synchronize()
+        assert lib.kd6d_barrier_timeouts() == 0 and lib.kd6d_ctx_barrier_timeouts(h) == 0
+        ops.check(lib.kd6d_ctx_make_current(None))
+        assert lib.kd6d_ctx_current() == default and ops.get_option("conv.halo") == -1
+        torch.testing.assert_close(y1, y0, rtol=2e-4, atol=2e-4)
+    finally:
+        lib.kd6d_ctx_make_current(None)
+        ops.check(lib.kd6d_ctx_destroy(h), "kd6d_ctx_destroy")
+    assert lib.kd6d_ctx_destroy(ctypes.c_void_p(default)) != 0        # the default context cannot be destroyed
