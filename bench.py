@@ -64,6 +64,10 @@ def parse():
     p.add_argument("--student", type=str, default="")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--frame", type=str, default="crop256", choices=["crop256", "full640"])
+    p.add_argument("--exchange", type=str, default="between", choices=["between", "overlap"],
+                   help="data-parallel exchange schedule: one all-reduce between the step's two graphs (default), or two "
+                        "slices captured inside the single step graph, the FPN + head slice beside the backbone sweep "
+                        "(kd6d/libs/distributed.py EXCHANGE_MODE)")
     p.add_argument("--rccl-single-rank", action="store_true",
                    help="under `torch.distributed.run --nproc-per-node 1`: run the N > 1 code path (RCCL communicator, "
                         "the all-reduce between the two graphs, barriers) on one GPU")
@@ -72,9 +76,10 @@ def parse():
     p.add_argument("--fuse-norm", type=str, default="", choices=["", "none", "teacher", "student", "both"],
                    help="A/B aid: which network's convolutions take the conv + normalisation launch (kd6d_conv2d_fwd_norm); "
                         "default = the engine's measured choice")
-    p.add_argument("--no-bn-on-load", action="store_true",
-                   help="A/B aid: the student's in-stage BatchNorm + LeakyReLU as separate launches instead of applied "
-                        "by the next block's convolution while it loads (kd6d_conv2d_fwd_block)")
+    p.add_argument("--bn-on-load", type=int, default=-1,
+                   help="A/B aid: the student's in-stage BatchNorm + LeakyReLU applied by the next block's convolution while it "
+                        "loads (kd6d_conv2d_fwd_block): 0 never, 1 where the next block is a 1x1 convolution, 2 every in-stage "
+                        "transition; default = the engine's measured choice")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` timings (child runs of the other configs)")
     p.add_argument("--no-launch-events", action="store_true",
@@ -272,12 +277,13 @@ def main():
     student = PoseModuleKD(make_cfg(args.student, args.precision), getattr(BB, args.student)())
     student.net.reset_parameters(seed=1)
     student = student.to(dev).train()
-    if args.no_bn_on_load or os.environ.get("KD6D_BN_ON_LOAD") == "0":      # (env: a one-off A/B run of round 3)
-        student.net.bn_on_load = False
+    if args.bn_on_load >= 0:
+        student.net.bn_on_load = args.bn_on_load
     if args.fuse_norm:
         teacher.net.fuse_norm = args.fuse_norm in ("teacher", "both")
         student.net.fuse_norm = args.fuse_norm in ("student", "both")
     D.SINGLE_RANK_EXCHANGE = bool(args.rccl_single_rank)
+    D.EXCHANGE_MODE = args.exchange
     route = D.init_exchange() if use_pg else "none"      # kd6d_comm_* over librccl (include/kd6d.h)
     if use_pg:
         D.broadcast_(student.net.store.params, 0)
@@ -437,6 +443,7 @@ def main():
                                               args.student, args.precision, B,
                                               "480x640 full frames" if full else "640x480 frames, 256x256 DZI crops"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "exchange": route,
+                          "exchange_schedule": (D.EXCHANGE_MODE if use_pg else "none"),
                           "launch": "eager" if gstep is None else ("hipGraph replay (%d graph%s/step)" % (
                               gstep.graphs_per_step, "" if gstep.graphs_per_step == 1 else "s") + (
                               "" if not gstep.pipeline else ", teacher(k+1) overlapped with student step(k)")),
@@ -518,10 +525,22 @@ def bench_dense(args, out_fd):
             el = float(t.item())
         ms = el / steps * 1e3
         pairs = passes * float(N) * float(M)
-        laneops = pairs * (2 * D + 8)               # fp32 lane operations per pair (an FMA counted once)
+        # which passes run where (csrc/sinkhorn_dense.hip): with D = 16 the gradient-free softmin passes go to the matrix
+        # pipe (inner products as six bf16 MFMAs on three-way split operands: 6 x 2 x 16 FLOP per pair) while
+        # eps >= 1.5e-4 diameter^2; the small-eps steps and the last, gradient-carrying extrapolation keep the
+        # difference form on the fp32 vector pipe ((2D + 8) lane-ops per pair, an FMA counted once)
+        eps_list = [diam * diam] + [float(np.exp(2 * np.log(diam) + i * 2 * np.log(kd["SCALING"]))) for i in range(n_eps - 2)] + [blur * blur]
+        on_mfma = D == 16 and ops.get_option("sinkhorn.dense_mfma") != 0
+        thr = 0.0 if ops.get_option("sinkhorn.dense_mfma") == 2 else 1.5e-4 * diam * diam
+        n_mfma = 4 * (1 + sum(1 for e in eps_list if e >= thr)) if on_mfma else 0
+        n_diff = passes - n_mfma
+        mfma_flop = n_mfma * float(N) * float(M) * 6 * 2 * D
+        laneops = n_diff * float(N) * float(M) * (2 * D + 8)
         peak = PEAK_F32 / 2                         # lane-ops/s of the fp32 vector pipes (157.3 TFLOP/s counts FMA twice)
         results.append({"blur": blur, "diameter": diam, "eps_steps": n_eps, "softmin_passes": passes,
+                        "passes_matrix_pipe": n_mfma, "passes_difference_form": n_diff,
                         "ms_per_image": ms, "images_per_s": world * 1e3 / ms, "pairs_per_s": pairs / (ms * 1e-3),
+                        "mfma_tflops_over_whole_time": mfma_flop / (ms * 1e-3) / 1e12,
                         "frac_of_fp32_vector_peak": laneops / (ms * 1e-3) / peak, "loss": float(loss),
                         "finite": bool(torch.isfinite(loss).all() and torch.isfinite(gx).all() and torch.isfinite(ga).all())})
     if world > 1:
@@ -537,10 +556,18 @@ def bench_dense(args, out_fd):
         "config": {"workload": "BASELINE config 5 (configs/dense16d.yaml): N = M = %d cells, D = %d, p=2, blur %s, scaling %s, "
                                "reach %s; the reference cannot run this size (geomloss needs KeOps above 5000^2 pairs)"
                                % (N, D, head["blur"], kd["SCALING"], kd["REACH"]), "parallelism": "replicas x%d" % world},
-        "roofline": {"bound": "valu-fp32", "kernel": "sinkhorn_dense softmin passes (online logsumexp, costs never stored)",
-                     "achieved": head["frac_of_fp32_vector_peak"] * PEAK_F32 / 2 / 1e12, "peak": PEAK_F32 / 2 / 1e12,
-                     "unit": "T lane-op/s (fp32 vector, FMA = 1)", "frac": head["frac_of_fp32_vector_peak"], "traffic": None,
-                     "basis": "(2D+8) lane-ops per (row, column) pair x pairs per image / wall time"},
+        "roofline": ({"bound": "mfma", "kernel": "dense_softmin_mfma_kernel (inner products of the gradient-free softmin passes: "
+                                                  "six v_mfma_f32_32x32x16_bf16 on three-way bf16-split fp32 operands per 32x32 pairs)",
+                      "achieved": head["mfma_tflops_over_whole_time"], "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                      "frac": head["mfma_tflops_over_whole_time"] * 1e12 / PEAK_BF16, "traffic": None,
+                      "basis": "192 FLOP per pair x pairs of the %d matrix-pipe passes / WALL time of the whole image (the %d "
+                               "difference-form passes -- %.0f %% of the fp32 vector peak over the same time -- included)"
+                               % (head["passes_matrix_pipe"], head["passes_difference_form"], 100 * head["frac_of_fp32_vector_peak"])}
+                     if head["passes_matrix_pipe"] else
+                     {"bound": "valu-fp32", "kernel": "sinkhorn_dense softmin passes (online logsumexp, costs never stored)",
+                      "achieved": head["frac_of_fp32_vector_peak"] * PEAK_F32 / 2 / 1e12, "peak": PEAK_F32 / 2 / 1e12,
+                      "unit": "T lane-op/s (fp32 vector, FMA = 1)", "frac": head["frac_of_fp32_vector_peak"], "traffic": None,
+                      "basis": "(2D+8) lane-ops per (row, column) pair x pairs per image / wall time"}),
         "all_blurs": results, "finite": all(r_["finite"] for r_ in results)}))
 
 
@@ -573,8 +600,8 @@ def secondary_runs(args):
                              dtype=d["dtype"], workload=d["config"]["workload"], finite=d.get("finite"),
                              roofline={k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")})
                 if "all_blurs" in d:
-                    entry["all_blurs"] = [{k: b[k] for k in ("blur", "ms_per_image", "images_per_s",
-                                                               "frac_of_fp32_vector_peak")} for b in d["all_blurs"]]
+                    entry["all_blurs"] = [{k: b[k] for k in ("blur", "ms_per_image", "images_per_s", "passes_matrix_pipe",
+                                                               "passes_difference_form")} for b in d["all_blurs"]]
         except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
             entry.update(ok=False, error=repr(e)[:400])
         entry["wall_s"] = time.perf_counter() - t0

@@ -225,6 +225,7 @@ int kd6d_device_cu_count(void);
  *   conv.halo      -1 auto | 0 off | 1 256x128, 2 128x128 (4 waves), 3 128x128, 4 128x64, 5 128x32, 6 192x128, 9 64x64,
  *                  11-15 the two-workgroups-per-CU twins (maps <= 32 wide): 128x128 on 4 / 8 waves, 128x64, 64x64, 128x32
  *   conv.halo_pairing  1 | 0 keep the one-workgroup-per-CU halo tiles on maps <= 32 wide
+ *   conv.halo_wide     1 | 0 maps 65 ... 80 wide (the 60 x 80 level of 480 x 640 full frames) stay off the halo-patch kernel
  *   conv.smallc    -1 auto | 0 off | 1 the resident-patch kernel also below 2^17 pixels
  *   conv.splitk    -1 auto | 0 off | tile*100 + splits (tile 1 = 128x64, 2 = 64x64)
  *   conv.tile      -1 auto | 0 register-staged kernel | 1 128x128, 2 128x64, 3 64x64 (LDS-DMA kernel)

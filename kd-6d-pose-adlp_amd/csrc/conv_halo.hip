@@ -325,7 +325,7 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
   r.single(r);
 }
 
-// 3x3/s1/p1 layers with C % 64 == 0 on maps at most 64 wide, both sides packed identically.
+// 3x3/s1/p1 layers with C % 64 == 0 on maps at most 80 wide, both sides packed identically.
 template <int MODE>
 bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st) {
   const int force = (int)kd6d_opt(KD6D_OPT_CONV_HALO);
@@ -339,7 +339,7 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
     if (q.in_w > wmax) wmax = q.in_w;
     rows += g->batch * q.in_h * q.in_w;
   }
-  if (wmax > 64) return false;
+  if (wmax > (kd6d_opt(KD6D_OPT_CONV_HALO_WIDE) != 0 ? 80 : 64)) return false;      // (80: the 60 x 80 level of 480 x 640 full frames)
   const int halo = wmax + 1;
   // measured on the step's layers (tools/bench_conv.py), all variants with 8 waves (2 per SIMD: with 4 waves
   // the same 128x128 tile is 25-40 % slower, one wave per SIMD cannot hide the LDS-DMA / fragment latency):
@@ -371,6 +371,8 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   // twin is as fast as its original or up to 40 % slower (chunk-boundary stalls, no partner to cover them); inside
   // the step the pairs give +4 % (4889-4918 -> 5097 images/s, interleaved runs; profiles/r02_halo_pairing.md)
   if (kd6d_opt(KD6D_OPT_CONV_HALO_PAIRING) != 0 && halo <= 33) {
+    // (96 x 128 tiles for the 342-tile tower shape -- 456 tiles on 512 slots instead of 86 CUs carrying two tiles of 128 x
+    //  128 and 170 one -- were built and measured in round 3: 5064-5099 against 5184-5192 images/s, interleaved; removed)
     if (pick == 3 || pick == 6) pick = 12;
     else if (pick == 4) pick = 13;
     else if (pick == 9) pick = 14;
@@ -383,6 +385,17 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   if (pick == 13) { launch_halo<128, 64, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }
   if (pick == 14) { launch_halo<64, 64, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }
   if (pick == 15) { launch_halo<128, 32, 4, 1, MODE, 33, false>(p, halo, rows, st); return true; }
+  if (halo > 65) {
+    // maps 65 ... 80 wide: the same tiles with the patch sized for a halo of 81 rows (the 256 x 128 tile then takes
+    // exactly the CU's 160 KB)
+    if (pick == 1) launch_halo<256, 128, 4, 2, MODE, 81>(p, halo, rows, st);
+    else if (pick == 3 || pick == 6) launch_halo<128, 128, 4, 2, MODE, 81>(p, halo, rows, st);
+    else if (pick == 4) launch_halo<128, 64, 4, 2, MODE, 81>(p, halo, rows, st);
+    else if (pick == 5) launch_halo<128, 32, 4, 1, MODE, 81>(p, halo, rows, st);
+    else if (pick == 9) launch_halo<64, 64, 4, 2, MODE, 81>(p, halo, rows, st);
+    else launch_halo<128, 128, 4, 2, MODE, 81>(p, halo, rows, st);
+    return true;
+  }
   if (pick == 1) launch_halo<256, 128, 4, 2, MODE>(p, halo, rows, st);
   else if (pick == 3) launch_halo<128, 128, 4, 2, MODE>(p, halo, rows, st);      // 8 waves on the 128x128 tile
   else if (pick == 4) launch_halo<128, 64, 4, 2, MODE>(p, halo, rows, st);

@@ -189,29 +189,88 @@ __global__ __launch_bounds__(kThreadsD) void dense_softmin_kernel(const DenseArg
 // ---------------------------------------------------------------------------
 // The same softmin on the matrix pipe (D = 16, no gradient): C_ij / eps = k (|r_i|^2 + |c_j|^2 - 2 r_i.c_j), so in the
 // exp2 domain  v_ij = H_j + (2 k2 r_i).c_j - k2 |r_i|^2  with  H_j = h_j log2e - k2 |c_j|^2.  The row term is constant
-// along j and is added after the logsumexp; the inner products come out of v_mfma_f32_32x32x2_f32 (exact fp32 products,
-// fp32 accumulation, the f32 vector rate but on the OTHER pipe), the accumulators start at H_j, and the VALU is left with
-// the online logsumexp: ~4 lane-ops per pair instead of ~40.  A = 32 columns (from LDS), B = 32 rows (in registers for
-// the whole launch), so a lane ends with 16 columns of ONE row: the running (max, sum) of a row lives in the two lanes
-// l, l + 32 and is merged once at the end.
+// along j and is added after the logsumexp; the VALU is left with the online logsumexp, ~4 lane-ops per pair instead
+// of ~40.  The inner products run on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split into three
+// bf16 pieces (hi + mid + lo = the 24-bit value exactly) and the six products of order <= 2^-16 -- hh, hm, mh, hl, lh,
+// mm -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (K = 16 = the code dimension: one instruction per
+// product), 6 x 32 cycles per 32 x 32 block.  (v_mfma_f32_32x32x2_f32 gives the same numbers but runs at the fp32
+// VECTOR rate and, measured, does not overlap the logsumexp: 8 x 64 cycles + the VALU work, 0.45 ms per launch; the
+// first version of this kernel.)  The columns' pieces do not depend on epsilon and are prepared once per call
+// (dense_split_kernel); the rows' operand (2 k2)(r - centre) is split by the lane that owns it at the start of a launch.
+// A = 32 columns (from LDS), B = 32 rows (registers), so a lane ends with 16 columns of ONE row: the running
+// (max, sum) of a row lives in the two lanes l, l + 32 and in the two waves that share the row group.
 // The expansion cancels: its absolute error is ~2^-22 (|r|^2 + |c|^2) whatever the distance, i.e. ~k2 2^-22 S in the
 // exponent.  Points are centred (S = spread^2 instead of |p|^2) and the host takes this kernel only while that stays
 // below the fp32 noise the difference form has anyway (eps >= kMfmaEpsRel * diameter^2; the last, gradient-carrying
 // extrapolation and the small-eps steps keep the difference form above).
 // ---------------------------------------------------------------------------
-constexpr int kMRows = 128;        // rows per workgroup: 4 waves x 32
-constexpr int kMTile = 128;        // columns per LDS tile: 4 blocks of 32
-constexpr int kMPitch = 12;        // floats per column and k-parity half (8 used): 48 B -> conflict-free ds_read_b128
+constexpr int kMRows = 64;         // rows per workgroup: 2 row groups of 32; the other two waves take the other column half
+constexpr int kMTile = 128;        // columns per LDS tile: 4 blocks of 32, two per wave
+constexpr int kSplitBytes = 96;    // prepared point: 3 pieces x 2 k-halves x 8 bf16
+constexpr int kMPitchB = 112;      // LDS bytes per column: 96 used; 28 dwords -> conflict-free ds_read_b128 over 16 columns
 
-__global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs a, const float* __restrict__ center) {
-  constexpr int D = 16;
-  __shared__ __attribute__((aligned(16))) float ce[2][2][kMTile * kMPitch];   // [buffer][k parity][column][k / 2]
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split3(float v, bf16_t& h, bf16_t& m, bf16_t& l) {
+  h = (bf16_t)v;
+  const float r1 = v - (float)h;
+  m = (bf16_t)r1;
+  l = (bf16_t)(r1 - (float)m);
+}
+
+// centred points -> MFMA-ready pieces [point][piece h,m,l][k half][8 bf16] + |p - centre|^2, once per call
+__global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ p, int n, const float* __restrict__ center,
+                                                          char* __restrict__ out, float* __restrict__ n2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  bf16_t h[16], m[16], l[16];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float v = p[(size_t)i * 16 + k] - center[k];
+    s += v * v;
+    split3(v, h[k], m[k], l[k]);
+  }
+  n2[i] = s;
+  bf16x8_t* o = reinterpret_cast<bf16x8_t*>(out + (size_t)i * kSplitBytes);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    bf16x8_t vh, vm, vl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { vh[e] = h[8 * half + e]; vm[e] = m[8 * half + e]; vl[e] = l[8 * half + e]; }
+    o[0 * 2 + half] = vh; o[1 * 2 + half] = vm; o[2 * 2 + half] = vl;
+  }
+}
+
+struct DenseSplit {
+  const char* xs; const char* ys;      // prepared points (kSplitBytes each)
+  const float* xn2; const float* yn2;  // |p - centre|^2
+};
+
+// online logsumexp over a lane's 16 columns of its row (padding columns are -inf)
+__device__ __forceinline__ void dense_lse_update(const f32x16_t& acc, float& m, float& s) {
+  float bm = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+  for (int u = 1; u < 4; ++u) bm = fmaxf(bm, fmaxf(fmaxf(acc[4 * u], acc[4 * u + 1]), fmaxf(acc[4 * u + 2], acc[4 * u + 3])));
+  const float mn = fmaxf(m, bm);
+  float add = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) add += __builtin_amdgcn_exp2f(acc[u] - mn);
+  s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+  m = mn;
+}
+
+__global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs a, const DenseSplit sp) {
+  __shared__ __attribute__((aligned(16))) char cs[2][kMTile * kMPitchB];
   __shared__ __attribute__((aligned(16))) float hs[2][kMTile];
+  __shared__ float mrg[kMRows * 2];
   const int which = blockIdx.y;
   const bool rows_x = (which == 0 || which == 3);
   const bool cols_x = (which == 0 || which == 2);
-  const float* R = rows_x ? a.x : a.y;
-  const float* Cc = cols_x ? a.x : a.y;
+  const char* Rs = rows_x ? sp.xs : sp.ys;
+  const float* Rn2 = rows_x ? sp.xn2 : sp.yn2;
+  const char* Cs = cols_x ? sp.xs : sp.ys;
+  const float* Cn2 = cols_x ? sp.xn2 : sp.yn2;
   const int nr = rows_x ? a.N : a.M;
   const int nc = cols_x ? a.N : a.M;
   const float* lw = cols_x ? a.la : a.lb;
@@ -219,49 +278,69 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   const int opot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_ay(a) : off_bx(a);
   if (blockIdx.x * kMRows >= nr) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5;                     // which k of each MFMA k-pair this lane feeds
-  const int row = blockIdx.x * kMRows + wave * 32 + (lane & 31);
+  const int rgrp = wave & 1;                      // which 32 rows of the workgroup
+  const int chalf = wave >> 1;                    // which two of the four 32-column blocks of every tile
+  const int half = lane >> 5;                     // which 8 of the 16 dimensions this lane feeds
+  const int lrow = rgrp * 32 + (lane & 31);
+  const int row = blockIdx.x * kMRows + lrow;
   const bool rok = row < nr;
   const float inv_eps = 1.f / a.eps;
   const float k2 = 0.5f * inv_eps * kLog2e;
-  // B operand: (2 k2)(r - centre), k = 2 kk + half; and the row term -k2 |r - centre|^2
-  float b[8];
-  float rr = 0.f;
+  // B operand: (2 k2)(r - centre) for k = 8 half .. 8 half + 7, rebuilt from the prepared pieces (their sum is the fp32
+  // value exactly) and split again after the scaling
+  bf16x8_t bh, bm_, bl;
+  {
+    const bf16x8_t* rp = reinterpret_cast<const bf16x8_t*>(Rs + (size_t)(rok ? row : 0) * kSplitBytes);
+    const bf16x8_t ph = rp[0 * 2 + half], pm = rp[1 * 2 + half], pl = rp[2 * 2 + half];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int k = 2 * kk + half;
-    const float v = rok ? R[(size_t)row * D + k] - center[k] : 0.f;
-    rr += v * v;
-    b[kk] = 2.f * k2 * v;
+    for (int e = 0; e < 8; ++e) {
+      const float v = rok ? ((float)ph[e] + (float)pm[e]) + (float)pl[e] : 0.f;
+      bf16_t h, m, l;
+      split3(2.f * k2 * v, h, m, l);
+      bh[e] = h; bm_[e] = m; bl[e] = l;
+    }
   }
-  rr += __shfl_xor(rr, 32, 64);
+  const float rr = rok ? Rn2[row] : 0.f;
 
   auto stage = [&](int buf, int c0) {
-    // 4 threads per column: a float4 of coordinates each -> even / odd k halves; |c|^2 over the quad; H_j
-    for (int i = tid; i < kMTile * 4; i += 256) {
-      const int c = i >> 2, q = i & 3;
-      f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-      const bool ok = c0 + c < nc;
-      if (ok) {
-        v = *reinterpret_cast<const f32x4_t*>(Cc + (size_t)(c0 + c) * D + 4 * q);
-        const f32x4_t ct = *reinterpret_cast<const f32x4_t*>(center + 4 * q);
-        v -= ct;
-      }
-      *reinterpret_cast<f32x2_t*>(&ce[buf][0][c * kMPitch + 2 * q]) = f32x2_t{v[0], v[2]};
-      *reinterpret_cast<f32x2_t*>(&ce[buf][1][c * kMPitch + 2 * q]) = f32x2_t{v[1], v[3]};
-      float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-      n2 += __shfl_xor(n2, 1, 64);
-      n2 += __shfl_xor(n2, 2, 64);
-      if (q == 0) {
-        float h = -INFINITY;
-        if (ok) {
-          h = lw[c0 + c];
-          if (a.mode != 0) h += a.pot_old[cpot + c0 + c] * inv_eps;
-          h = h * kLog2e - k2 * n2;
-        }
-        hs[buf][c] = h;
-      }
+    // 6 x 16 B per column, copied as they are; H_j from this launch's potentials
+    for (int i = tid; i < kMTile * 6; i += 256) {
+      const int c = i / 6, q = i - c * 6;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (c0 + c < nc) v = *reinterpret_cast<const u32x4_t*>(Cs + (size_t)(c0 + c) * kSplitBytes + q * 16);
+      *reinterpret_cast<u32x4_t*>(&cs[buf][c * kMPitchB + q * 16]) = v;
     }
+    for (int c = tid; c < kMTile; c += 256) {
+      float h = -INFINITY;
+      if (c0 + c < nc) {
+        h = lw[c0 + c];
+        if (a.mode != 0) h += a.pot_old[cpot + c0 + c] * inv_eps;
+        h = h * kLog2e - k2 * Cn2[c0 + c];
+      }
+      hs[buf][c] = h;
+    }
+  };
+
+  auto block = [&](int buf, int blk) {
+    f32x16_t acc;
+    const float* hb = &hs[buf][blk * 32];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(hb + 4 * half + 8 * u);
+      acc[4 * u + 0] = h4[0]; acc[4 * u + 1] = h4[1]; acc[4 * u + 2] = h4[2]; acc[4 * u + 3] = h4[3];
+    }
+    const char* col = &cs[buf][(blk * 32 + (lane & 31)) * kMPitchB + half * 16];
+    const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(col);
+    const bf16x8_t am = *reinterpret_cast<const bf16x8_t*>(col + 32);
+    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(col + 64);
+    // smallest products first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm_, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm_, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
   };
 
   float m = -1e30f, s = 0.f;
@@ -271,48 +350,30 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * kMTile);
-    const float* cA = &ce[buf][half][0];
-#pragma unroll
-    for (int blk = 0; blk < kMTile / 32; ++blk) {
-      typedef float f32x16_t __attribute__((ext_vector_type(16)));
-      f32x16_t acc;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(&hs[buf][blk * 32 + 4 * half + 8 * u]);
-        acc[4 * u + 0] = h4[0]; acc[4 * u + 1] = h4[1]; acc[4 * u + 2] = h4[2]; acc[4 * u + 3] = h4[3];
-      }
-      const float* col = cA + (blk * 32 + (lane & 31)) * kMPitch;
-      const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(col);
-      const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(col + 4);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2], b[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], b[3], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b[4], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b[5], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], b[6], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], b[7], acc, 0, 0, 0);
-      // online logsumexp over this lane's 16 columns of its row (padding columns are -inf)
-      float bm = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-#pragma unroll
-      for (int u = 1; u < 4; ++u) bm = fmaxf(bm, fmaxf(fmaxf(acc[4 * u], acc[4 * u + 1]), fmaxf(acc[4 * u + 2], acc[4 * u + 3])));
-      const float mn = fmaxf(m, bm);
-      float add = 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) add += __builtin_amdgcn_exp2f(acc[u] - mn);
-      s = s * __builtin_amdgcn_exp2f(m - mn) + add;
-      m = mn;
-    }
+    // this wave's two blocks: both MFMA chains are issued before the first logsumexp, so the matrix pipe works on the
+    // second block while the VALU reduces the first
+    const f32x16_t acc0 = block(buf, 2 * chalf);
+    const f32x16_t acc1 = block(buf, 2 * chalf + 1);
+    dense_lse_update(acc0, m, s);
+    dense_lse_update(acc1, m, s);
     __syncthreads();
   }
-  // the two lanes of a row
+  // the two lanes of a row, then the two column halves (waves w and w + 2)
   {
     const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
     const float mn = fmaxf(m, m2);
     s = s * __builtin_amdgcn_exp2f(m - mn) + s2 * __builtin_amdgcn_exp2f(m2 - mn);
     m = mn;
   }
-  if (half != 0 || !rok) return;
+  if (chalf == 1 && half == 0) { mrg[2 * lrow] = m; mrg[2 * lrow + 1] = s; }
+  __syncthreads();
+  if (chalf != 0 || half != 0 || !rok) return;
+  {
+    const float m2 = mrg[2 * lrow], s2 = mrg[2 * lrow + 1];
+    const float mn = fmaxf(m, m2);
+    s = s * __builtin_amdgcn_exp2f(m - mn) + s2 * __builtin_amdgcn_exp2f(m2 - mn);
+    m = mn;
+  }
   const float lse = (m + __builtin_amdgcn_logf(s) - k2 * rr) * kLn2;
   const float val = -a.lam * a.eps * lse;
   if (a.mode == 1) a.pot_new[opot + row] = 0.5f * (a.pot_old[opot + row] + val);
@@ -423,9 +484,19 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   float* potB = potA + 2 * (size_t)(N + M);
   float* gxx = potB + 2 * (size_t)(N + M);
   float* gxy = gxx + (size_t)N * D;
-  float* center = gxy + (size_t)N * D;            // 16 floats (the workspace's 64-float tail)
+  float* center = gxy + (size_t)N * D;            // 16 floats (of the 64-float pad)
+  float* n2 = center + 64;                        // (N + M) floats, then the prepared points: (N + M) x 96 B
+  char* splits = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(n2 + (size_t)(N + M)) + 15) & ~(uintptr_t)15);
   const bool use_mfma = D == 16 && kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) != 0;
-  if (use_mfma) hipLaunchKernelGGL(dense_center_kernel, dim3(1), dim3(256), 0, st, x, y, N, M, D, center);
+  DenseSplit sp;
+  sp.xs = splits; sp.ys = splits + (size_t)N * kSplitBytes; sp.xn2 = n2; sp.yn2 = n2 + N;
+  if (use_mfma) {
+    hipLaunchKernelGGL(dense_center_kernel, dim3(1), dim3(256), 0, st, x, y, N, M, D, center);
+    hipLaunchKernelGGL(dense_split_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, N, (const float*)center,
+                       splits, n2);
+    hipLaunchKernelGGL(dense_split_kernel, dim3((M + 255) / 256), dim3(256), 0, st, y, M, (const float*)center,
+                       splits + (size_t)N * kSplitBytes, n2 + N);
+  }
   hipLaunchKernelGGL(dense_logw_kernel, dim3((N + 255) / 256), dim3(256), 0, st, alpha, la, N);
   hipLaunchKernelGGL(dense_logw_kernel, dim3((M + 255) / 256), dim3(256), 0, st, beta, lb, M);
   // epsilon schedule in double, like the reference's python floats (geomloss epsilon_schedule, p = 2)
@@ -457,7 +528,7 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
     a.pot_old = cur; a.pot_new = nxt; a.mode = mode; a.eps = (float)eps;
     a.lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
     if (!grad && use_mfma && eps >= mfma_eps_min) {
-      if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, (const float*)center);
+      if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, sp);
     } else if (grad) hipLaunchKernelGGL((dense_softmin_kernel<D, true>), grid, dim3(kThreadsD), 0, st, a);
     else hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
     float* t = cur; cur = nxt; nxt = t;
@@ -481,7 +552,9 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
 }  // namespace
 
 extern "C" int64_t kd6d_sinkhorn_dense_workspace_floats(int N, int M, int D) {
-  return (int64_t)N + M + 4 * ((int64_t)N + M) + 2 * (int64_t)N * D + 64;
+  // log weights, two potential sets, two gradient partials, centre (+ pad), and for D = 16 the matrix-pipe softmin's
+  // prepared points: |p|^2 and 96 bytes of bf16 pieces per point
+  return (int64_t)N + M + 4 * ((int64_t)N + M) + 2 * (int64_t)N * D + 64 + (D == 16 ? 25 * ((int64_t)N + M) + 16 : 0);
 }
 
 extern "C" int kd6d_sinkhorn_dense_diameter(const float* x, const float* y, int N, int M, int D, float* scratch64,

@@ -68,6 +68,9 @@ def get_argparser():
     p.add_argument("--two_launch_norm_bwd", action="store_true",
                    help="BatchNorm / GroupNorm backward as reduce + apply launches instead of one launch with an "
                         "in-kernel barrier (the remedy train_kd.py names when a barrier wait timed out)")
+    p.add_argument("--exchange", type=str, default="between", choices=["between", "overlap"],
+                   help="data-parallel gradient exchange: one all-reduce between the step's two graphs, or two slices inside "
+                        "the step (FPN + head beside the backbone sweep; kd6d/libs/distributed.py EXCHANGE_MODE)")
     p.add_argument("--mixed_classes", type=str2bool, nargs="?", const=True, default=None,
                    help="synthetic batches mix the 13 LINEMOD classes (default: DATASETS.MIXED_CLASSES of the yaml)")
     return p
@@ -97,7 +100,7 @@ def _runtime(args, config_file, weight_file):
     return dict(LOCAL_RANK=args.local_rank, CONFIG_FILE=config_file, NUM_WORKERS=args.num_workers,
                 WEIGHT_FILE=weight_file, RUNNING_DEVICE=args.running_device, PRECISION=args.precision,
                 TEACHER_PNP_GATE=bool(args.teacher_pnp_gate),
-                TWO_LAUNCH_NORM_BWD=bool(args.two_launch_norm_bwd))
+                TWO_LAUNCH_NORM_BWD=bool(args.two_launch_norm_bwd), EXCHANGE=args.exchange)
 
 
 def build_cfgs(args):

@@ -432,18 +432,24 @@ class PoseNet:
         self.use_wgrad_group = True
         self.wgrad_group_wgs = 0
         self.wgrad_group_flush = "head_end"     # or "fpn_end" (GraphedKDStep picks by launch mode)
+        self.grad_hook = None           # called by backward() when the FPN + head gradients have been issued
         self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
         # conv + normalisation + activation as one launch (kd6d_conv2d_fwd_norm: in-kernel barrier in the conv epilogue).
-        # None = the measured choice: the head towers of an EVAL-mode network (the frozen teacher: the fp32
-        # pre-normalisation tensor is then not even stored, +0.4 ... +1.1 % on the step) but NOT the training network --
-        # a workgroup that waits at a barrier keeps its LDS and wave slots while the other stream's kernels could use
-        # them: student towers fused -3 %, student BatchNorm blocks fused -1.2 % (interleaved runs on one box,
-        # profiles/README.md round 3); a kernel boundary is the cheaper barrier when two streams share the device.
+        # Measured on the step, interleaved runs on one box (profiles/README.md round 3): the frozen teacher's towers
+        # fused (the fp32 pre-normalisation tensor is then not even stored) +0.4 ... +1.1 % on config 2 but -1.8 % on
+        # config 4's shard and -1.2 % on full frames; the student's towers fused -3 %, its BatchNorm blocks -1.2 %.  A
+        # workgroup that waits at a barrier keeps its LDS and wave slots while the other stream's kernels could use them:
+        # a kernel boundary is the cheaper barrier when two streams share the device.  Off (None = off); the entry point,
+        # its tests and the residency argument (csrc/kd6d_barrier.h) stay for single-stream callers.
         self.fuse_norm = None
-        # inside a stage of the student's backbone a block's BatchNorm + LeakyReLU is applied by the NEXT block's
-        # convolution while it loads its input (kd6d_conv2d_fwd_block): 10 of the 15 normalise launches (and the 3
-        # separate statistics passes of stage 3) leave the forward chain, without any wait inside a kernel
-        self.bn_on_load = True
+        # inside a stage of the student's backbone a block's BatchNorm + LeakyReLU can be applied by the NEXT block's
+        # convolution while it loads its input (kd6d_conv2d_fwd_block): up to 10 of the 15 normalise launches (and the 3
+        # separate statistics passes of stage 3) leave the forward chain without any wait inside a kernel.  Measured
+        # (interleaved runs on one box, round 3): 0 -> 5192 / 5212 images/s, 1 -> 5151 / 5172, 2 -> 5187: the
+        # register-staged kernel that can transform on load gives back what the removed launches save (the 3x3 layers
+        # leave the LDS-DMA kernels and re-read the fp32 tensor once per tap).  Off by default; kept, tested, for
+        # layer mixes where the normalise launches weigh more.
+        self.bn_on_load = 0            # 0 off | 1 where the next block is a 1x1 convolution | 2 every in-stage transition
         # cls / pose tower layers as one launch (training): 0 = off, 1 = forward and data gradients, 2 = forward only
         self.pair_towers = 1
         self._side_rr = 0
@@ -583,7 +589,7 @@ class PoseNet:
     WORKSPACE_BYTES = 64 << 20      # split-K partial slabs (fp32) of the few-tile / long-K layers
 
     def fuse_norm_on(self):
-        return (not self.training) if self.fuse_norm is None else bool(self.fuse_norm)
+        return False if self.fuse_norm is None else bool(self.fuse_norm)
 
     def next_side_stream(self):
         if self.side_streams:
@@ -672,8 +678,9 @@ class PoseNet:
                     # inside a stage the next block applies this block's BatchNorm + LeakyReLU while loading its input
                     # (one launch per block instead of conv [+ statistics] + normalise): stages 3-5; the first two
                     # stages are single blocks
+                    nxt_pointwise = (not last) and units[j + 1].conv.k == 1
                     x, lv, pending = u.fwd_train(x, B, lv, self.tape, pool=(i != n - 1 and last), pending=pending,
-                                                 defer=self.bn_on_load and not last)
+                                                 defer=self.bn_on_load == 2 and not last or (self.bn_on_load == 1 and nxt_pointwise))
                 if i != n - 1:
                     self.tape.append(("pooled", i))
                 feats.append((x, lv))
@@ -921,6 +928,10 @@ class PoseNet:
         ops.mark("student.bwd.fpn.end")
         if self.wgrad_group is not None and self.wgrad_group_flush == "fpn_end":
             self.flush_wgrad_group()
+        if self.grad_hook is not None:
+            # every gradient outside the backbone has been issued (on this stream or on the weight-gradient streams):
+            # a data-parallel caller starts their exchange here, beside the backbone sweep
+            self.grad_hook()
         # ---- backbone (tiny): walk the tape in reverse ----
         # feats index -> gradient arriving from the FPN; out4 = index 3 (after stage 5), out3 = index 2
         grad = dfeat[top]

@@ -37,7 +37,7 @@ class GraphedKDStep:
     WGRAD_BUDGET_DIV = {True: 2.0, False: 4.0}
 
     def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3,
-                 concurrent=True, pipeline=False):
+                 concurrent=True, pipeline=False, exchange=None):
         self.teacher, self.student, self.opt = teacher, student, optimizer
         # fork/join inside the captured graph: the teacher's forward runs beside the student's, and the weight
         # gradients beside the dgrad / normalisation chain (many of these kernels fill < 256 CUs on their own)
@@ -72,18 +72,47 @@ class GraphedKDStep:
         self._nhwc = None                                  # pipeline: (current, next) packed NHWC inputs inside them
         self.pending = False
         self.primed = False                                # pipeline: the teacher has seen a batch the student has not
+        # data-parallel exchange schedule (kd6d/libs/distributed.py EXCHANGE_MODE): "between" the two graphs, or
+        # "overlap" = two slices captured inside the single step graph, the big one beside the backbone sweep
+        self.exchange = exchange or D.EXCHANGE_MODE
+        assert self.exchange in ("between", "overlap")
+        self.comm_stream = None
+        self._split = None
 
     # ---- the body the reference's loop runs per iteration (train_kd.py:104-137) ----------
+    def _overlap(self):
+        return self.exchange == "overlap" and D.exchange_active()
+
+    def _early_exchange(self):
+        """PoseNet.backward calls this when the FPN + head gradients have been issued: their all-reduce goes out on the
+        communication stream, behind everything the weight-gradient streams and the sweep's stream hold so far."""
+        snet = self.student.net
+        comm = self.comm_stream
+        for side in [torch.cuda.current_stream()] + list(snet.side_streams or ([snet.side_stream] if snet.side_stream else [])):
+            comm.wait_stream(side)
+        with torch.cuda.stream(comm):
+            D.exchange_slice(snet.store, self._split, snet.store.n_train)
+
     def _student_step(self, pred_t):
         if self._w is None:
             self._w = torch.tensor([self.w_cls, self.w_reg, self.w_kd], dtype=torch.float32,
                                    device=self.student.net.device)
         snet = self.student.net
         snet.nhwc_in = self._nhwc[0] if self._nhwc is not None else None
+        overlap = self._overlap()
+        if overlap:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+                self._split = D.bucket_split(snet.store)
+            snet.grad_hook = self._early_exchange
         try:
             losses = self.student.step_losses(self.images, self.tgt, pred_t, self._w)
         finally:
             snet.nhwc_in = None
+            snet.grad_hook = None
+        if overlap:        # the sweep has joined its side streams: the backbone's slice, behind the big one
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            D.exchange_slice(snet.store, 0, self._split)
         return {"loss_cls": losses[0], "loss_reg": losses[1], "loss_kd": losses[2]}
 
     def _teacher(self, images, tgt):
@@ -225,7 +254,7 @@ class GraphedKDStep:
         # Without a gradient exchange (one rank) nothing has to happen between the reverse sweep and the optimiser:
         # ONE graph per step, and the eager kd6d_set_hyper launch moves in front of it.  With an exchange the RCCL
         # all-reduce sits between two graphs.
-        self.graphs_per_step = 2 if D.exchange_active() else 1
+        self.graphs_per_step = 2 if (D.exchange_active() and not self._overlap()) else 1
         self.g_step = torch.cuda.CUDAGraph()
         # thread-local capture mode: with a process group alive, RCCL's watchdog thread polls events concurrently
         with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
@@ -239,7 +268,8 @@ class GraphedKDStep:
         self._restore(snap)
 
     def _exchange(self):
-        D.exchange_gradients(self.student.net.store)
+        if not self._overlap():            # (overlap: both slices were issued inside the step already)
+            D.exchange_gradients(self.student.net.store)
 
     def _count_opt_step(self):
         # torch's lr schedulers count optimizer.step() calls to warn about ordering

@@ -145,6 +145,39 @@ def allreduce_mean_(flat):
     return flat
 
 
+# How the per-step exchange is scheduled (bench.py --exchange, train_kd.py --exchange):
+#   "between"  one mean all-reduce of the whole trainable slice, issued eagerly BETWEEN the step's two replayed graphs
+#              (backward | optimiser).  The default: every piece of it has run on hardware at world size 1 and its
+#              arithmetic at world size 2 (gloo); nothing about it depends on capturing a collective.
+#   "overlap"  two slices.  The FPN + head gradients (90 % of the tiny-H bucket) are final when the reverse sweep leaves
+#              the FPN, 0.6 ms before the step ends: their all-reduce goes out there on a side stream and runs beside the
+#              backbone sweep; the backbone's small slice follows when the sweep has joined.  GraphedKDStep captures
+#              both collectives INSIDE the step's single graph (RCCL supports stream capture), so no launch gap and no
+#              host call is left on the step's critical path.  Validated at world size 1 on hardware (rehearsal) and at
+#              world size 2 on CPU (eager, gloo); opt-in until an N > 1 box has replayed a captured collective.
+EXCHANGE_MODE = "between"
+
+
+def bucket_split(store):
+    """First element of the FPN + head part of the flat gradient bucket (the backbone's gradients lie before it: the
+    parameter store registers backbone, FPN, head in that order)."""
+    first = None
+    for e in store.order:
+        if e.region != "train":
+            continue
+        if e.name.startswith("backbone."):
+            assert first is None, "backbone entry %s behind a non-backbone entry" % e.name
+        elif first is None:
+            first = e.offset
+    return store.n_train if first is None else first
+
+
+def exchange_slice(store, lo, hi):
+    """Mean over ranks of grads[lo:hi] (asynchronous on the current stream)."""
+    if exchange_active() and hi > lo:
+        allreduce_mean_(store.grads[lo:hi])
+
+
 def exchange_gradients(store):
     """THE exchange step of the data-parallel path: mean over ranks of the trainable slice of the flat gradient
     bucket.  Parameters the reference registers but never gives a gradient (backbone.output.*, head.scales.4 of a

@@ -314,8 +314,26 @@ class PoseModuleKD(nn.Module):
             dreg.zero_()
         self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.storage(net.scales, "grads"))
         ops.mark("student.bwd.start")
-        net.backward(dcls, dreg)
-        ops.mark("student.bwd.end")
         from ..libs import distributed as D
-        if not getattr(self, "_defer_allreduce", False):   # GraphedKDStep issues it between its two graphs
+        own = not getattr(self, "_defer_allreduce", False)      # GraphedKDStep schedules the exchange itself
+        split = D.bucket_split(st) if (own and D.exchange_active() and D.EXCHANGE_MODE == "overlap") else None
+        if split is not None:
+            comm = self._comm_stream = getattr(self, "_comm_stream", None) or torch.cuda.Stream()
+
+            def early():
+                for side in [torch.cuda.current_stream()] + list(net.side_streams or ([net.side_stream] if net.side_stream else [])):
+                    comm.wait_stream(side)
+                with torch.cuda.stream(comm):
+                    D.exchange_slice(st, split, st.n_train)
+            net.grad_hook = early
+        try:
+            net.backward(dcls, dreg)
+        finally:
+            if split is not None:
+                net.grad_hook = None
+        ops.mark("student.bwd.end")
+        if split is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            D.exchange_slice(st, 0, split)
+        elif own:
             D.exchange_gradients(st)

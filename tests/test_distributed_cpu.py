@@ -40,7 +40,18 @@ def _worker(rank, world, port, out):
     assert D.exchange_route() == "torch.distributed (gloo)"
     D.exchange_gradients(st)
     frozen = sorted(e.name for e in st.order if e.region == "frozen")
-    out[rank] = (g.clone(), p.clone(), st.grads.clone(), st.n_train, frozen)
+    # the two-slice schedule (EXCHANGE_MODE "overlap": FPN + head first, the backbone's slice afterwards) moves exactly
+    # the same elements: every trainable gradient once, nothing behind n_train
+    split = D.bucket_split(st)
+    two = torch.full((st.params.numel(),), float(rank + 1))
+    one = st.grads
+    st.grads = two
+    D.exchange_slice(st, split, st.n_train)
+    head_done = two.clone()
+    D.exchange_slice(st, 0, split)
+    st.grads = one
+    names_before = [e.name for e in st.order if e.region == "train" and e.offset < split]
+    out[rank] = (g.clone(), p.clone(), st.grads.clone(), st.n_train, frozen, two.clone(), head_done, split, names_before)
     dist.destroy_process_group()
 
 
@@ -52,13 +63,18 @@ def test_allreduce_mean_and_broadcast_world2():
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     exp = torch.arange(1000, dtype=torch.float32) * 1.5
     for r in range(world):
-        g, p, bucket, n_train, frozen = out[r]
+        g, p, bucket, n_train, frozen, two, head_done, split, names_before = out[r]
         assert torch.equal(g, exp)
         assert torch.equal(p, torch.zeros(64))
         assert 2_200_000 < n_train < bucket.numel()
         assert torch.equal(bucket[:n_train], torch.full((n_train,), 1.5))              # mean of rank gradients
         assert torch.equal(bucket[n_train:], torch.full((bucket.numel() - n_train,), float(r + 1)))
         assert frozen == ["backbone.output.final_conv.bias", "backbone.output.final_conv.weight", "head.scales.4.scale"]
+        assert torch.equal(two, bucket)                                               # two slices == one all-reduce
+        assert 0 < split < 0.15 * n_train                                             # the backbone is the small slice
+        assert names_before and all(n.startswith("backbone.") for n in names_before)
+        assert torch.equal(head_done[split:n_train], torch.full((n_train - split,), 1.5))
+        assert torch.equal(head_done[:split], torch.full((split,), float(r + 1)))    # ... not exchanged yet at that point
 
 
 def test_single_process_helpers():

@@ -8,20 +8,22 @@ QUICK=${2:-}
 mkdir -p $O
 cd $R
 if [ -z "$QUICK" ]; then
-  timeout 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/pytest_gpu.txt
+  timeout 3000 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/pytest_gpu.txt
   grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 >> $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 fi
 python bench.py > $O/bench_pipelined.json 2> $O/bench_pipelined.err
-python bench.py --no-pipeline --no-cpu-baseline > $O/bench_nopipeline.json 2> $O/bench_nopipeline.err
-python bench.py --steps 30 --warmup 10 --no-cpu-baseline --timeline > /dev/null 2> $O/timeline_pipelined.txt
-python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-pipeline --timeline > /dev/null 2> $O/timeline_nopipeline.txt
+python bench.py --no-pipeline --no-cpu-baseline --no-secondary > $O/bench_nopipeline.json 2> $O/bench_nopipeline.err
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-secondary --timeline > /dev/null 2> $O/timeline_pipelined.txt
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-secondary --no-pipeline --timeline > /dev/null 2> $O/timeline_nopipeline.txt
 if [ -z "$QUICK" ]; then
   python bench.py --workload linemod13 --no-cpu-baseline > $O/bench_linemod13.json 2>/dev/null
   python bench.py --workload dense16d > $O/bench_dense16d.json 2>/dev/null
-  python bench.py --student darknet_tiny --no-cpu-baseline > $O/bench_darknet_tiny.json 2>/dev/null
+  python bench.py --student darknet_tiny --no-cpu-baseline --no-secondary > $O/bench_darknet_tiny.json 2>/dev/null
   python bench.py --frame full640 --no-cpu-baseline --steps 30 > $O/bench_full640.json 2>/dev/null
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --rccl-single-rank --no-cpu-baseline > $O/bench_rccl_single_rank.json 2> $O/bench_rccl_single_rank.err
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --rccl-single-rank --no-cpu-baseline --no-secondary > $O/bench_rccl_single_rank.json 2> $O/bench_rccl_single_rank.err
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --rccl-single-rank --exchange overlap --no-cpu-baseline --no-secondary > $O/bench_rccl_single_rank_overlap.json 2> $O/bench_rccl_single_rank_overlap.err
+  python bench.py --no-cpu-baseline --no-secondary > $O/bench_pipelined_again.json 2>/dev/null
   python tools/bench_norm.py > $O/bench_norm.md 2>&1
   python tools/bench_conv.py --kind all --set all > $O/bench_conv.md 2>&1
   python tools/bench_wgrad_group.py > $O/bench_wgrad_group.txt 2>&1
@@ -29,11 +31,11 @@ if [ -z "$QUICK" ]; then
   rm -rf $O/train/*.pth
 fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o kd -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o kd -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/prof.log 2>&1
 cd $R
 DB=$(ls $O/prof/*/kd_results.db $O/prof/kd_results.db 2>/dev/null | tail -1)
 python tools/rocprof_summary.py $DB $O/kernel_stats.md 29 > /dev/null
 python tools/step_sequence.py $DB $O/step_dispatches.md > $O/step_dispatches_head.txt 2>&1
 rm -rf $O/prof
 cat $O/pytest_gpu.txt $O/smoke.txt 2>/dev/null; tail -2 $O/train.log 2>/dev/null; cat $O/step_dispatches_head.txt
-for f in pipelined nopipeline linemod13 darknet_tiny full640 rccl_single_rank; do [ -s $O/bench_$f.json ] && python -c "import json; d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value'],1), round(d['ms_per_step'],3), d['finite'], d['roofline']['frac'] if 'roofline' in d else None)"; done
+for f in pipelined pipelined_again nopipeline linemod13 darknet_tiny full640 rccl_single_rank rccl_single_rank_overlap; do [ -s $O/bench_$f.json ] && python -c "import json; d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value'],1), round(d['ms_per_step'],3), d['finite'], d['roofline']['frac'] if 'roofline' in d else None)"; done

@@ -118,6 +118,8 @@ if __name__ == "__main__":
     if cfg["RUNTIME"]["DISTRIBUTED"]:
         torch.distributed.init_process_group(backend="nccl", init_method="env://")
         synchronize()
+        from kd6d.libs import distributed as _D
+        _D.EXCHANGE_MODE = cfg["RUNTIME"].get("EXCHANGE", "between")
         print("gradient exchange: " + init_exchange())      # kd6d_comm_* over librccl (include/kd6d.h)
 
     if cfg["RUNTIME"]["SYNTHETIC"]:
