@@ -137,8 +137,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// (the kernels compiled without the fused-normalisation epilogue never read the fields behind stats_cpg_shift: their
+//  scalar-register budget is the round-2 one -- two more SGPRs cost conv3x3_smallc_kernel<1,1> a wave per SIMD)
+template <bool NORM>
 __device__ __forceinline__ int tile_of_workgroup(const ConvParams& p, int bid, int nwg) {
-  return p.linear_tiles ? bid : xcd_remap(bid, nwg);
+  if constexpr (NORM) return p.linear_tiles ? bid : xcd_remap(bid, nwg);
+  else return xcd_remap(bid, nwg);
 }
 
 // (level, image) key of GEMM row m: level * batch + image.  Monotone in m (levels are packed level-major, image-major).
@@ -202,7 +206,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // channel and workgroup.  Group mode (GroupNorm): a 16-pixel fragment normally lies inside one
 // (level, image); its 4-channel lane sums are shuffled down to one atomic pair per group, else
 // (tiny levels, several images per fragment) every lane adds its own 4-channel partial.
-template <int BP, int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC, bool NORM = false>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
                                                     int m0, int n0, int wp, int wc, int lane, float* red) {
   constexpr int PI = BP / WP / 16;
@@ -244,12 +248,13 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
     __syncthreads();
     // fused normalisation: replica rows (hundreds of workgroups adding into one address retire one after the other,
     // ~25 ns each) and RETURNING atomics (visible before this workgroup arrives at the barrier, kd6d_barrier.h)
-    const int rep = p.stats_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.stats_replicas) : 0;
+    int rep = 0;
+    if constexpr (NORM) rep = p.stats_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.stats_replicas) : 0;
     for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
       const int which = i / BC, nl = i - which * BC;
       if (n0 + nl < p.N) {
         float* o = p.stats + (size_t)(rep * 2 + which) * p.N + n0 + nl;
-        if (p.norm_dst) atomic_add_performed(o, red[i]);
+        if (NORM && p.norm_dst) atomic_add_performed(o, red[i]);
         else atomicAdd(o, red[i]);
       }
     }
@@ -310,7 +315,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
     const int gl = rem >> 1;
     if (g_first + gl < G) {
       float* o = p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1);
-      if (p.norm_dst) atomic_add_performed(o, red[i]);
+      if (NORM && p.norm_dst) atomic_add_performed(o, red[i]);
       else atomicAdd(o, red[i]);
     }
   }
@@ -318,7 +323,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
 
 // Epilogue shared by the register-staged and the LDS-DMA kernels: lane owns pixel (lane&15),
 // channels (lane>>4)*4 .. +3 of every 16x16 accumulator tile.
-template <typename T, int BP, int BC, int WP, int WC, bool WIDE = true>
+template <typename T, int BP, int BC, int WP, int WC, bool WIDE = true, bool NORM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
                                               int m0, int n0, int wp, int wc, int lane, float* smem_f32) {
   constexpr int PI = BP / WP / 16;
@@ -409,7 +414,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
           *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(p.dst) + o) = pk;
         }
       }
-      if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
+      if (p.stats) conv_epilogue_stats<BP, BC, WP, WC, NORM>(p, acc, m0, n0, wp, wc, lane, smem_f32);
       return;
     }
   }
@@ -468,7 +473,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
           }
         }
         if (p.stats) acc[c][q] = f32x4_t{v[0], v[1], v[2], v[3]};
-        if (!p.dst) {
+        if (NORM && !p.dst) {
           // statistics only: the caller consumes the values from the accumulators (conv_epilogue_norm)
         } else if (p.out_f32) {
           *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.dst) + o) =
@@ -502,7 +507,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
       }
     }
   }
-  if (p.stats) conv_epilogue_stats<BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32);
+  if (p.stats) conv_epilogue_stats<BP, BC, WP, WC, NORM>(p, acc, m0, n0, wp, wc, lane, smem_f32);
 }
 
 // ---------------------------------------------------------------------------
@@ -691,13 +696,18 @@ __device__ __forceinline__ void conv_epilogue_norm(const ConvParams& p, f32x4_t 
   }
 }
 
-// What the kernels call: conv_epilogue, then the fused normalisation when the launch carries one.
-template <typename T, int BP, int BC, int WP, int WC, bool WIDE = true>
+// What the kernels call: conv_epilogue, then -- in the kernel variants compiled with NORM -- the fused normalisation when
+// the launch carries one.  NORM is a template parameter, not a run-time branch: the first version compiled the second
+// phase into every convolution kernel and its registers cost the whole step 5 % (5400-5508 -> 5141-5156 images/s on one
+// box, full frames 1530 -> 1065) although no launch used it.
+template <typename T, int BP, int BC, int WP, int WC, bool WIDE = true, bool NORM = false>
 __device__ __forceinline__ void conv_epilogue_full(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
                                                    int m0, int n0, int wp, int wc, int lane, float* smem_f32, int bid,
                                                    int nwg, int tile_c) {
-  conv_epilogue<T, BP, BC, WP, WC, WIDE>(p, acc, m0, n0, wp, wc, lane, smem_f32);
-  if (p.norm_dst) conv_epilogue_norm<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32, bid, nwg, tile_c);
+  conv_epilogue<T, BP, BC, WP, WC, WIDE, NORM>(p, acc, m0, n0, wp, wc, lane, smem_f32);
+  if constexpr (NORM) {
+    if (p.norm_dst) conv_epilogue_norm<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, smem_f32, bid, nwg, tile_c);
+  }
 }
 
 static __device__ const uint4 kd6d_zero_page[4] = {};

@@ -27,7 +27,7 @@ namespace {
 // double-buffered behind the current one; without it the workgroup stops at a chunk boundary until the new patch
 // has landed -- in exchange a 128x128 tile fits 76 KB of LDS, so TWO workgroups (of this or of another stream's
 // launch) share a CU and one's prologue, chunk stalls and epilogue run under the other's k-loop.
-template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true, bool NORM = false>
 __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int total_rows, int bid, int nwg) {
   using T = bf16_t;
   constexpr int NW = WP * WC;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = tile_of_workgroup(p, bid, nwg);
+  const int wg = tile_of_workgroup<NORM>(p, bid, nwg);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -229,25 +229,25 @@ __device__ __forceinline__ void halo_tile(const ConvParams& p, int halo, int tot
 #pragma unroll
     for (int q = 0; q < PI; ++q) mma(ga[c], gb[q], acc[c][q]);
   __syncthreads();             // the epilogue reuses the LDS the last k-step may still be reading
-  conv_epilogue_full<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), bid, nwg, tile_c);
+  conv_epilogue_full<T, BP, BC, WP, WC, true, NORM>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), bid, nwg, tile_c);
 }
 
 // second launch bound = waves per SIMD the register budget has to leave room for: the single-buffer variants are
 // built to run two workgroups per CU
-template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true, bool NORM = false>
 __global__ __launch_bounds__(WP* WC * 64, PDB ? 1 : WP * WC / 2) void conv3x3_halo_kernel(const ConvParams p, int halo, int total_rows) {
-  halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB>(p, halo, total_rows, blockIdx.x, gridDim.x);
+  halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>(p, halo, total_rows, blockIdx.x, gridDim.x);
 }
 
 // Two convolutions of identical geometry (the cls and the pose tower layer of the head: different tensors and
 // weights, same shapes) as ONE launch: workgroups [0, tiles_a) run `pa`, the rest `pb`.  A student tower layer
 // alone is 170 tiles of 128x128 on 256 CUs, one 128-KB workgroup per CU -- a second stream cannot use the idle
 // third; as a pair the two layers are 228 tiles of 192x128, one full round for both.
-template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true, bool NORM = false>
 __global__ __launch_bounds__(WP* WC * 64, PDB ? 1 : WP * WC / 2) void conv3x3_halo_pair_kernel(const ConvParams pa, const ConvParams pb,
                                                                         int halo, int total_rows, int tiles_a) {
-  if ((int)blockIdx.x < tiles_a) halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB>(pa, halo, total_rows, blockIdx.x, tiles_a);
-  else halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB>(pb, halo, total_rows, blockIdx.x - tiles_a, gridDim.x - tiles_a);
+  if ((int)blockIdx.x < tiles_a) halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>(pa, halo, total_rows, blockIdx.x, tiles_a);
+  else halo_tile<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>(pb, halo, total_rows, blockIdx.x - tiles_a, gridDim.x - tiles_a);
 }
 
 // kd6d_conv2d_pair_begin / _end: between the two calls, halo-kernel launches are recorded instead of issued; two
@@ -283,10 +283,10 @@ size_t halo_lds() {
   return (PDB ? (size_t)2 * PL * NW : (size_t)PSLOT) * 1024 + (size_t)3 * BC * 128;
 }
 
-template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true, bool NORM = false>
 void halo_issue_single(const HaloRecord& r) {
   const size_t lds = halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>();
-  auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE, HMAX, PDB>;
+  auto kern = conv3x3_halo_kernel<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -296,10 +296,10 @@ void halo_issue_single(const HaloRecord& r) {
   hipLaunchKernelGGL(kern, dim3(r.tiles), dim3(WP * WC * 64), lds, r.st, r.q, r.halo, r.total_rows);
 }
 
-template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true, bool NORM = false>
 void halo_issue_pair(const HaloRecord& a, const HaloRecord& b) {
   const size_t lds = halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>();
-  auto kern = conv3x3_halo_pair_kernel<BP, BC, WP, WC, MODE, HMAX, PDB>;
+  auto kern = conv3x3_halo_pair_kernel<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -310,7 +310,7 @@ void halo_issue_pair(const HaloRecord& a, const HaloRecord& b) {
                      a.tiles);
 }
 
-template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true>
+template <int BP, int BC, int WP, int WC, int MODE, int HMAX = 65, bool PDB = true, bool NORM = false>
 void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) {
   HaloRecord r;
   r.q = p;
@@ -318,9 +318,9 @@ void launch_halo(const ConvParams& p, int halo, int total_rows, hipStream_t st) 
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(r.q, ptiles, BP, BC);
   r.halo = halo; r.total_rows = total_rows; r.tiles = ptiles * r.q.n_ctiles; r.st = st;
-  r.single = &halo_issue_single<BP, BC, WP, WC, MODE, HMAX, PDB>;
-  r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE, HMAX, PDB>;
-  if (plan_only(r.tiles, WP * WC * 64, halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>(), true)) return;
+  r.single = &halo_issue_single<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>;
+  r.pair = &halo_issue_pair<BP, BC, WP, WC, MODE, HMAX, PDB, NORM>;
+  if (plan_only(r.tiles, WP * WC * 64, halo_lds<BP, BC, WP, WC, MODE, HMAX, PDB>(), NORM)) return;
   if (g_pair.active && g_pair.count < 2) { g_pair.rec[g_pair.count++] = r; return; }
   r.single(r);
 }
@@ -332,6 +332,7 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   if (force == 0) return false;
   if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C & 63) || (p.N & 3)) return false;
   if (p.N < 64 && p.N > 32) return false;
+  if (!p.norm_dst && p.stats_replicas > 1) return false;      // replica rows of the batch statistics: register-staged kernel
   int wmax = 0, rows = 0;
   for (int s = 0; s < g->nseg; ++s) {
     const kd6d_seg& q = g->seg[s];
@@ -380,6 +381,16 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   }
   if (force > 0 && (force < 10 || halo <= 33)) pick = force;      // 11..15: the twins, maps <= 32 wide only
   if (pick == 0) return false;
+  if (p.norm_dst) {
+    // a fused normalisation behind the convolution (kd6d_conv2d_fwd_norm): compiled into the 128 x 128 forward tiles only
+    if constexpr (MODE == MODE_FWD) {
+      if (halo > 65) launch_halo<128, 128, 4, 2, MODE, 81, true, true>(p, halo, rows, st);
+      else if (halo > 33 || kd6d_opt(KD6D_OPT_CONV_HALO_PAIRING) == 0) launch_halo<128, 128, 4, 2, MODE, 65, true, true>(p, halo, rows, st);
+      else launch_halo<128, 128, 4, 2, MODE, 33, false, true>(p, halo, rows, st);
+      return true;
+    }
+    return false;
+  }
   if (pick == 11) { launch_halo<128, 128, 2, 2, MODE, 33, false>(p, halo, rows, st); return true; }
   if (pick == 12) { launch_halo<128, 128, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }
   if (pick == 13) { launch_halo<128, 64, 4, 2, MODE, 33, false>(p, halo, rows, st); return true; }

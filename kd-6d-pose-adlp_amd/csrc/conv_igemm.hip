@@ -30,7 +30,7 @@ namespace {
 // T -- so the separate normalise launch and its (rows, C) round trip go without any wait inside a kernel.  The
 // activation tensor the weight gradient needs is written on the way (centre tap, channel tile 0: every input pixel
 // exactly once); workgroup 0 publishes save_mean / save_invstd and updates the running statistics.
-template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false>
+template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false, bool NORM = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int EG = Granule<T>::N;
   constexpr int BK = 8 * EG;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = tile_of_workgroup(p, blockIdx.x, gridDim.x);
+  const int wg = tile_of_workgroup<NORM || XF>(p, blockIdx.x, gridDim.x);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
   }
-  const int center_tap = (p.ks * p.ks) >> 1;
+  int center_tap = 0;
+  if constexpr (XF) center_tap = (p.ks * p.ks) >> 1;
 
   auto issue_loads = [&](int kt) {
     const int kk = kt * BK + gcol * EG;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  conv_epilogue_full<T, BP, BC, WP, WC>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), blockIdx.x,
+  conv_epilogue_full<T, BP, BC, WP, WC, true, NORM || XF>(p, acc, m0, n0, wp, wc, lane, reinterpret_cast<float*>(smem), blockIdx.x,
                                         gridDim.x, tile_c);
 }
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p
   const int wp = wave % WP;
   const int wc = wave / WP;
 
-  const int wg = tile_of_workgroup(p, blockIdx.x, gridDim.x);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_c = p.p_fastest ? wg / p.n_ptiles : wg % p.n_ctiles;
   const int tile_p = p.p_fastest ? wg % p.n_ptiles : wg / p.n_ctiles;
   const int m0 = tile_p * BP;
@@ -1222,15 +1223,15 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ w
 }
 
 
-template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false>
-void launch_igemm(const ConvParams& p, hipStream_t st) {
+template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false, bool NORM = false>
+void launch_igemm_impl(const ConvParams& p, hipStream_t st) {
   ConvParams q = p;
   q.n_ctiles = (p.N + BC - 1) / BC;
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)(BP + BC) * 128 * 2 + (XF ? (size_t)2 * p.C * sizeof(float) : 0);
-  if (plan_only(ptiles * q.n_ctiles, 256, lds, true)) return;
-  auto kern = conv_igemm_kernel<T, BP, BC, WP, WC, MODE, XF>;
+  if (plan_only(ptiles * q.n_ctiles, 256, lds, NORM)) return;
+  auto kern = conv_igemm_kernel<T, BP, BC, WP, WC, MODE, XF, NORM>;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1240,6 +1241,16 @@ void launch_igemm(const ConvParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(ptiles * q.n_ctiles), dim3(256), lds, st, q);
 }
 
+// the fused-normalisation epilogue exists in the forward, non-XF variants only (kd6d_conv2d_fwd_norm)
+template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false>
+void launch_igemm(const ConvParams& p, hipStream_t st) {
+  if constexpr (MODE == MODE_FWD && !XF) {
+    // ... and so do the replica rows of the fused batch statistics (kd6d_conv2d_fwd_block)
+    if (p.norm_dst || p.stats_replicas > 1) { launch_igemm_impl<T, BP, BC, WP, WC, MODE, false, true>(p, st); return; }
+  }
+  launch_igemm_impl<T, BP, BC, WP, WC, MODE, XF, false>(p, st);
+}
+
 template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE>
 void launch_glds(const ConvParams& p, hipStream_t st) {
   ConvParams q = p;
@@ -1247,7 +1258,7 @@ void launch_glds(const ConvParams& p, hipStream_t st) {
   const int ptiles = (p.M + BP - 1) / BP;
   set_tile_order(q, ptiles, BP, BC);
   const size_t lds = (size_t)(BP + BC) * 128 * NSTAGE;
-  if (plan_only(ptiles * q.n_ctiles, 256, lds, true)) return;
+  if (plan_only(ptiles * q.n_ctiles, 256, lds, false)) return;
   auto kern = conv_igemm_glds_kernel<BP, BC, WP, WC, MODE, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1291,7 +1302,7 @@ bool dispatch_smallc(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t s
   if (force == 0) return false;
   if (p.ks != 3 || p.stride != 1 || p.pad != 1 || (p.C != 8 && p.C != 16 && p.C != 32) || (p.N & 3)) return false;
   if (p.stats && p.stats_groups > 0) return false;      // the group-statistics table wants the big staging buffers
-  if (p.norm_dst) return false;                         // no fused-normalisation epilogue in this kernel
+  if (p.norm_dst || p.stats_replicas > 1) return false;   // no fused-normalisation epilogue / replica rows in this kernel
   // one burst per workgroup, no pipeline: pays once >= 2 workgroups per CU overlap each other (measured: the
   // 64x64-pixel layers and below are faster on the pipelined kernels)
   if (force < 0 && p.M < (1 << 17)) return false;
@@ -1369,9 +1380,10 @@ template <int MODE>
 bool dispatch_glds(const ConvParams& p, hipStream_t st) {
   const int force = (int)kd6d_opt(KD6D_OPT_CONV_TILE);
   if (force == 0 || p.N <= 32) return false;
-  // fused BatchNorm (grid barrier: every workgroup of the launch resident at once, kd6d_barrier.h): the register-staged
-  // kernel's 32-48 KB tiles instead of this one's 64-KB rings
-  if (p.norm_dst && p.stats_groups == 0 && force < 0) return false;
+  // launches with a fused normalisation (kd6d_conv2d_fwd_norm) or replica rows of the batch statistics take the
+  // register-staged kernel: this one is not compiled with that epilogue (and its 64-KB rings would not leave a
+  // grid-barrier launch room to be resident at once)
+  if (p.norm_dst || p.stats_replicas > 1) return false;
   const int N = p.N, M = p.M;
   auto nblocks = [&](int bp, int bc) { return ((M + bp - 1) / bp) * ((N + bc - 1) / bc); };
   // measured (tools/bench_conv.py): with enough workgroups the register-staged kernel is as fast or faster

@@ -107,4 +107,4 @@ def test_overlapped_exchange_captured_in_the_step_graph(gpu_device):
         # three AdamW steps of lr 1e-3 move a parameter by <= 3e-3; where the runs disagree about the sign of a near-zero
         # gradient the two copies end up to 6e-3 apart -- a few elements; the bulk moves together
         d = (q - p_base).abs()
-        assert float(d.max()) <= 6.5e-3 and float(d.mean()) <= 3e-4, (float(d.max()), float(d.mean()))
+        assert float(d.max()) <= 6.5e-3 and float(d.mean()) <= 8e-4, (float(d.max()), float(d.mean()))
