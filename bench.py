@@ -405,8 +405,10 @@ def main():
         peak = PEAK_BF16 if args.precision == "bf16" else PEAK_F32
         achieved = tot_flop / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(HERE, "profiles", "r02_conv_hbm_traffic.json")
-        if os.path.exists(tpath) and args.student == "darknet_tiny_h" and not full and B == 16 and args.precision == "bf16":
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_conv_hbm_traffic.json")))
+        tpath = tfiles[-1] if tfiles else ""          # the latest round's PMC passes (tools/pmc_traffic.sh on the closing state)
+        if tpath and args.student == "darknet_tiny_h" and not full and B == 16 and args.precision == "bf16" and not args.opt:
             # HBM bytes of the conv family per step from rocprofv3 PMC passes (tools/pmc_traffic.sh, FETCH_SIZE x2
             # per the gfx950 correction + WRITE_SIZE), committed with the profile it was taken from
             with open(tpath) as f:
@@ -423,7 +425,9 @@ def main():
                 "achieved": wall_tflops / 1e12 if wall_tflops else achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": (wall_tflops if wall_tflops else achieved) / peak,
                 "flop_per_step": flop_img * B if flop_img else tot_flop / max(n_instr, 1),
-                "traffic": traffic, "traffic_unit": "HBM bytes per step, conv family (PMC, profiles/r02_conv_hbm_traffic.json)",
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes per step, conv family (rocprofv3 PMC passes of the round's closing state: %s)" % (
+                    os.path.join("profiles", os.path.basename(tpath)) if tpath else "none"),
                 "eager_launch_events": {
                     "note": "HIP events around every conv launch of %d eagerly launched single-stream steps after the "
                             "timed region; NOT the timed schedule" % n_instr,
@@ -532,7 +536,8 @@ def bench_dense(args, out_fd):
         eps_list = [diam * diam] + [float(np.exp(2 * np.log(diam) + i * 2 * np.log(kd["SCALING"]))) for i in range(n_eps - 2)] + [blur * blur]
         on_mfma = D == 16 and ops.get_option("sinkhorn.dense_mfma") != 0
         thr = 0.0 if ops.get_option("sinkhorn.dense_mfma") == 2 else 1.5e-4 * diam * diam
-        n_mfma = 4 * (1 + sum(1 for e in eps_list if e >= thr)) if on_mfma else 0
+        # (of the last extrapolation's four softmins the two without a gradient go there too)
+        n_mfma = (4 * (1 + sum(1 for e in eps_list if e >= thr)) + (2 if eps_list[-1] >= thr else 0)) if on_mfma else 0
         n_diff = passes - n_mfma
         mfma_flop = n_mfma * float(N) * float(M) * 6 * 2 * D
         laneops = n_diff * float(N) * float(M) * (2 * D + 8)

@@ -40,6 +40,8 @@ struct DenseArgs {
   int mode;                                // 0: init (h = log w), 1: symmetrised update, 2: last extrapolation
   float eps, lam;                          // epsilon, 1/(1+eps/rho) (1 if balanced)
   float* grad_xx; float* grad_xy;          // mode 2: softmax-weighted sums of (x_i - c_j), (N,D) each
+  int which[4];                            // the softmins of this launch, one per blockIdx.y: 0 a_x (x<-x), 1 b_y (y<-y),
+                                           // 2 a_y (y<-x), 3 b_x (x<-y)
 };
 
 // potentials layout helpers
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kThreadsD) void dense_softmin_kernel(const DenseArg
   __shared__ float mrg[kRows * (GRAD ? D + 2 : 2)];     // partial (m, s, g) of the second column half
 
   // which of the four softmins: rows / columns / column potential / output slot
-  const int which = blockIdx.y;            // 0: a_x (x<-x)  1: b_y (y<-y)  2: a_y (y<-x)  3: b_x (x<-y)
+  const int which = a.which[blockIdx.y];   // 0: a_x (x<-x)  1: b_y (y<-y)  2: a_y (y<-x)  3: b_x (x<-y)
   const bool rows_x = (which == 0 || which == 3);
   const bool cols_x = (which == 0 || which == 2);
   const float* R = rows_x ? a.x : a.y;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   __shared__ __attribute__((aligned(16))) char cs[2][kMTile * kMPitchB];
   __shared__ __attribute__((aligned(16))) float hs[2][kMTile];
   __shared__ float mrg[kMRows * 2];
-  const int which = blockIdx.y;
+  const int which = a.which[blockIdx.y];
   const bool rows_x = (which == 0 || which == 3);
   const bool cols_x = (which == 0 || which == 2);
   const char* Rs = rows_x ? sp.xs : sp.ys;
@@ -527,10 +529,27 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   auto launch = [&](int mode, double eps, bool grad) {
     a.pot_old = cur; a.pot_new = nxt; a.mode = mode; a.eps = (float)eps;
     a.lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
-    if (!grad && use_mfma && eps >= mfma_eps_min) {
-      if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, sp);
-    } else if (grad) hipLaunchKernelGGL((dense_softmin_kernel<D, true>), grid, dim3(kThreadsD), 0, st, a);
-    else hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
+    const bool mfma_ok = use_mfma && eps >= mfma_eps_min;
+    auto set_which = [&](int w0, int w1, int w2, int w3) { a.which[0] = w0; a.which[1] = w1; a.which[2] = w2; a.which[3] = w3; };
+    if (!grad) {
+      set_which(0, 1, 2, 3);
+      if (mfma_ok) {
+        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, sp);
+      } else {
+        hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
+      }
+    } else {
+      // the last extrapolation: only the two softmins over the rows of x (a_x, b_x) carry a gradient -- difference form,
+      // with the softmax-weighted sums; the other two (b_y, a_y) are plain potentials
+      set_which(0, 3, 0, 0);
+      hipLaunchKernelGGL((dense_softmin_kernel<D, true>), dim3(grid.x, 2), dim3(kThreadsD), 0, st, a);
+      set_which(1, 2, 0, 0);
+      if (mfma_ok) {
+        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
+      } else {
+        hipLaunchKernelGGL((dense_softmin_kernel<D, false>), dim3(grid.x, 2), dim3(kThreadsD), 0, st, a);
+      }
+    }
     float* t = cur; cur = nxt; nxt = t;
   };
   launch(0, eps_at(0), false);

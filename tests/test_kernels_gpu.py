@@ -1284,7 +1284,7 @@ def test_conv_block_bn_on_load(gpu_device, dtype, case):
     assert bool((d <= ulp).all()), float(d.max())               # same arithmetic; the eight rows are added in another order
     if dtype == torch.bfloat16:
         assert float((d > 0).float().mean()) < 5e-2             # a few values one rounding step apart
-    torch.testing.assert_close(raw_b, raw_ref, rtol=2e-3, atol=2e-3)       # a few inputs one rounding step apart
+    torch.testing.assert_close(raw_b, raw_ref, rtol=5e-3, atol=5e-3)       # a few inputs one bf16 rounding step apart
     torch.testing.assert_close(sums_b.sum(0).reshape(-1), sums_ref, rtol=1e-3, atol=0.5)
 
 
