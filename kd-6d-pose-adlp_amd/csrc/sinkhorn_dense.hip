@@ -22,9 +22,11 @@
 
 namespace {
 
-constexpr int kRows = 256;        // rows per workgroup
-constexpr int kSplit = 2;         // threads per row: each takes every kSplit-th half of a column tile, merged at the end
-constexpr int kThreadsD = kRows * kSplit;   // 512 threads = 2 waves per SIMD: a lone wave issues one VALU op per 4+ clk
+constexpr int kThreadsD = 512;    // 2 waves per SIMD: a lone wave issues one VALU op per 4+ clk
+constexpr int kRows = 256;        // rows per workgroup of the default form: kSplit = 2 threads per row, each takes its share
+constexpr int kSplit = 2;         // of every column tile, merged at the end; the gradient form of the last extrapolation
+                                  // runs on two of the four softmins only and takes SPLIT = 4 (128 rows per workgroup) so
+                                  // that it still yields one workgroup per CU at N = 16384
 constexpr int kTile = 128;        // columns staged per LDS tile (kTile / kSplit per thread)
 constexpr float kNegLogD = -100000.f;
 constexpr float kLog2e = 1.4426950408889634f;
@@ -50,11 +52,14 @@ __device__ __forceinline__ int off_bx(const DenseArgs& a) { return a.N; }
 __device__ __forceinline__ int off_by(const DenseArgs& a) { return 2 * a.N; }
 __device__ __forceinline__ int off_ay(const DenseArgs& a) { return 2 * a.N + a.M; }
 
-template <int D, bool GRAD>
+template <int D, bool GRAD, int SPLIT = kSplit>
 __global__ __launch_bounds__(kThreadsD) void dense_softmin_kernel(const DenseArgs a) {
   constexpr int P = (D + 4) & ~3;          // LDS pitch: D coords + h (+ pad), a multiple of 16 bytes
+  constexpr int kRows = kThreadsD / SPLIT;
+  constexpr int kSplit = SPLIT;
+  constexpr int MW = GRAD ? D + 2 : 2;     // floats of a partial (m, s, g)
   __shared__ __attribute__((aligned(16))) float tile[2][kTile * P];
-  __shared__ float mrg[kRows * (GRAD ? D + 2 : 2)];     // partial (m, s, g) of the second column half
+  __shared__ float mrg[(SPLIT - 1) * kRows * MW];       // partials of the other column shares
 
   // which of the four softmins: rows / columns / column potential / output slot
   const int which = a.which[blockIdx.y];   // 0: a_x (x<-x)  1: b_y (y<-y)  2: a_y (y<-x)  3: b_x (x<-y)
@@ -152,26 +157,29 @@ __global__ __launch_bounds__(kThreadsD) void dense_softmin_kernel(const DenseArg
     }
     __syncthreads();
   }
-  // merge the column shares of a row: logsumexp of two partial (max, sum) pairs
-  if (part == 1) {
-    mrg[lrow * (GRAD ? D + 2 : 2) + 0] = m;
-    mrg[lrow * (GRAD ? D + 2 : 2) + 1] = s;
+  // merge the column shares of a row: logsumexp of the partial (max, sum) pairs
+  if (part != 0) {
+    float* o = mrg + ((part - 1) * kRows + lrow) * MW;
+    o[0] = m;
+    o[1] = s;
     if (GRAD) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) mrg[lrow * (D + 2) + 2 + d] = g[d];
+      for (int d = 0; d < D; ++d) o[2 + d] = g[d];
     }
   }
   __syncthreads();
   if (part != 0 || !rok) return;
-  {
-    const float m2 = mrg[lrow * (GRAD ? D + 2 : 2) + 0], s2 = mrg[lrow * (GRAD ? D + 2 : 2) + 1];
+#pragma unroll
+  for (int q = 1; q < SPLIT; ++q) {
+    const float* o = mrg + ((q - 1) * kRows + lrow) * MW;
+    const float m2 = o[0], s2 = o[1];
     const float mn = fmaxf(m, m2);
     const float c1 = m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f;
     const float c2 = m2 > -INFINITY ? __builtin_amdgcn_exp2f(m2 - mn) : 0.f;
     s = s * c1 + s2 * c2;
     if (GRAD) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) g[d] = g[d] * c1 + mrg[lrow * (D + 2) + 2 + d] * c2;
+      for (int d = 0; d < D; ++d) g[d] = g[d] * c1 + o[2 + d] * c2;
     }
     m = mn;
   }
@@ -542,7 +550,7 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
       // the last extrapolation: only the two softmins over the rows of x (a_x, b_x) carry a gradient -- difference form,
       // with the softmax-weighted sums; the other two (b_y, a_y) are plain potentials
       set_which(0, 3, 0, 0);
-      hipLaunchKernelGGL((dense_softmin_kernel<D, true>), dim3(grid.x, 2), dim3(kThreadsD), 0, st, a);
+      hipLaunchKernelGGL((dense_softmin_kernel<D, true, 4>), dim3((nmax + 127) / 128, 2), dim3(kThreadsD), 0, st, a);
       set_which(1, 2, 0, 0);
       if (mfma_ok) {
         if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
