@@ -85,6 +85,9 @@ def parse():
     p.add_argument("--no-launch-events", action="store_true",
                    help="skip the eagerly launched, HIP-event-instrumented steps behind roofline.eager_launch_events")
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    p.add_argument("--teacher-group", type=int, default=1,
+                   help="pipelined launch only: run the frozen teacher over the batches of this many consecutive steps at "
+                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step")
     p.add_argument("--no-pipeline", action="store_true",
                    help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
     p.add_argument("--cpu-steps", type=int, default=4)
@@ -303,14 +306,20 @@ def main():
     if args.no_graph:
         gstep = None
     else:
-        gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
+        if args.teacher_group > 1 and not args.no_pipeline:
+            from kd6d.graph import GroupedTeacherKDStep
+            gstep = GroupedTeacherKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=args.teacher_group)
+        else:
+            gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
+    group = getattr(gstep, "group", 1)
     if args.timeline and gstep is not None:
         ops.marks_begin(dev)                     # before the capture: the markers become graph nodes
     n_prime = 0
     if gstep is not None and gstep.pipeline:
-        # priming call: teacher only, no student step yet
-        assert gstep(*batches[0]) is None
-        n_prime = 1
+        # priming call(s): teacher only, no student step yet
+        n_prime = 1 if group == 1 else 2 * group      # (grouped: one period loading, one with the teacher on it)
+        for j in range(n_prime):
+            assert gstep(*batches[j % len(batches)]) is None
 
     def step(i, eager=False):
         images, tgt = batches[i % len(batches)]
@@ -333,15 +342,22 @@ def main():
         sched.step()
         return ld
 
-    for i in range(args.warmup):
+    # grouped teacher: every `group`-th call carries the teacher pass over `group` batches.  The timed region must not
+    # undercount it: extra untimed calls shift the phase so that the LAST timed call is one with a pass, i.e. the region
+    # holds ceil(steps / group) passes (>= steps * B images through the teacher)
+    n_align = (-(args.warmup + args.steps)) % group
+    for i in range(args.warmup + n_align):
         step(i)
+    step_base = args.warmup + n_align
+    passes0 = getattr(gstep, "teacher_passes", 0)
     if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ld = step(args.warmup + i)
+        ld = step(step_base + i)
     t_enqueued = time.perf_counter() - t0          # host-side launch time (the GPU runs behind)
+    passes_timed = getattr(gstep, "teacher_passes", 0) - passes0
     torch.cuda.synchronize()
     if use_pg:
         dist.barrier()
@@ -450,7 +466,12 @@ def main():
                           "exchange_schedule": (D.EXCHANGE_MODE if use_pg else "none"),
                           "launch": "eager" if gstep is None else ("hipGraph replay (%d graph%s/step)" % (
                               gstep.graphs_per_step, "" if gstep.graphs_per_step == 1 else "s") + (
-                              "" if not gstep.pipeline else ", teacher(k+1) overlapped with student step(k)")),
+                              "" if not gstep.pipeline else (", teacher(k+1) overlapped with student step(k)" if group == 1 else
+                                                             ", teacher over the %d batches of steps k+%d..k+%d in one pass every "
+                                                             "%d steps, beside a student step" % (group, 1, group, group)))),
+                          "teacher_group": group,
+                          "teacher_passes_in_timed_region": passes_timed if group > 1 else args.steps,
+                          "teacher_images_in_timed_region": (passes_timed * group * B) if group > 1 else args.steps * B,
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
                "losses_last_step": losses, "finite": finite, "barrier_timeouts": barrier_timeouts,
                "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,

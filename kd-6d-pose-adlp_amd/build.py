@@ -20,6 +20,11 @@ FLAGS = [
 ]
 
 
+# per-source additions.  sinkhorn_dense.hip: keep MFMA results in VGPRs -- the logsumexp that follows reads every one
+# of them on the VALU, and out of AGPRs that is one v_accvgpr_read per value (16 % of the kernel's vector work)
+EXTRA_FLAGS = {"sinkhorn_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -39,6 +44,7 @@ def _source_digest(src, base):
     h = base.copy()
     with open(os.path.join(CSRC, src), "rb") as f:
         h.update(f.read())
+    h.update(" ".join(EXTRA_FLAGS.get(src, [])).encode())
     return h.hexdigest()
 
 
@@ -69,7 +75,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -229,10 +229,13 @@ __device__ __forceinline__ void split3(float v, bf16_t& h, bf16_t& m, bf16_t& l)
 }
 
 // centred points -> MFMA-ready pieces [point][piece h,m,l][k half][8 bf16] + |p - centre|^2, once per call
-__global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ p, int n, const float* __restrict__ center,
-                                                          char* __restrict__ out, float* __restrict__ n2) {
+__global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ p, int n, const float* __restrict__ sums,
+                                                          float inv_count, char* __restrict__ out, float* __restrict__ n2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  float center[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) center[k] = sums[k] * inv_count;
   bf16_t h[16], m[16], l[16];
   float s = 0.f;
 #pragma unroll
@@ -257,16 +260,28 @@ struct DenseSplit {
   const float* xn2; const float* yn2;  // |p - centre|^2
 };
 
-// online logsumexp over a lane's 16 columns of its row (padding columns are -inf)
-__device__ __forceinline__ void dense_lse_update(const f32x16_t& acc, float& m, float& s) {
-  float bm = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// online logsumexp over a lane's 2 x 16 columns of its row (padding columns are -inf).  Written for the vector pipe,
+// which bounds this kernel: the maximum as ONE chain (v_max3_f32 takes two new values per instruction; a tree of
+// fmaxf pairs made the compiler quiet every leaf with a v_max_f32 x, x first: 26 instructions per 16 values instead
+// of 8), differences and sums two columns per instruction (v_pk_add_f32), one rescale of the running sum per tile.
+__device__ __forceinline__ void dense_lse_update(const f32x16_t& a0, const f32x16_t& a1, float& m, float& s) {
+  float mn = m;
 #pragma unroll
-  for (int u = 1; u < 4; ++u) bm = fmaxf(bm, fmaxf(fmaxf(acc[4 * u], acc[4 * u + 1]), fmaxf(acc[4 * u + 2], acc[4 * u + 3])));
-  const float mn = fmaxf(m, bm);
-  float add = 0.f;
+  for (int u = 0; u < 8; ++u) mn = fmaxf(fmaxf(mn, a0[2 * u]), a0[2 * u + 1]);
 #pragma unroll
-  for (int u = 0; u < 16; ++u) add += __builtin_amdgcn_exp2f(acc[u] - mn);
-  s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+  for (int u = 0; u < 8; ++u) mn = fmaxf(fmaxf(mn, a1[2 * u]), a1[2 * u + 1]);
+  const f32x2_t mn2 = {mn, mn};
+  f32x2_t add = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const f32x2_t d0 = f32x2_t{a0[2 * u], a0[2 * u + 1]} - mn2;
+    const f32x2_t d1 = f32x2_t{a1[2 * u], a1[2 * u + 1]} - mn2;
+    add += f32x2_t{__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+    add += f32x2_t{__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+  }
+  s = s * __builtin_amdgcn_exp2f(m - mn) + (add[0] + add[1]);
   m = mn;
 }
 
@@ -312,23 +327,39 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   }
   const float rr = rok ? Rn2[row] : 0.f;
 
-  auto stage = [&](int buf, int c0) {
-    // 6 x 16 B per column, copied as they are; H_j from this launch's potentials
-    for (int i = tid; i < kMTile * 6; i += 256) {
-      const int c = i / 6, q = i - c * 6;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (c0 + c < nc) v = *reinterpret_cast<const u32x4_t*>(Cs + (size_t)(c0 + c) * kSplitBytes + q * 16);
-      *reinterpret_cast<u32x4_t*>(&cs[buf][c * kMPitchB + q * 16]) = v;
+  // Column tiles travel global -> registers -> LDS: fetch() issues the loads of tile t + 1 before tile t is multiplied,
+  // put() stores them behind it (the first version loaded, waited and stored chunk by chunk inside the tile loop: three
+  // exposed L2 round trips per tile and workgroup).  A tile is 128 x 96 contiguous bytes = 768 chunks of 16 B, three per
+  // thread; chunk i is piece q = i % 6 of column i / 6.  H_j comes from this launch's potentials (threads 0 .. 127).
+  int ldst[3], scol[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + 256 * j;
+    scol[j] = i / 6;
+    ldst[j] = scol[j] * kMPitchB + (i - scol[j] * 6) * 16;
+  }
+  u32x4_t sv[3];
+  float s_lw = 0.f, s_pot = 0.f, s_n2 = 0.f;      // the three inputs of H_j as loaded; combined in put(), behind the wait
+  const bool with_pot = a.mode != 0;
+  auto fetch = [&](int c0) {
+    const char* g = Cs + (size_t)c0 * kSplitBytes + (size_t)tid * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      sv[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c0 + scol[j] < nc) sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * 4096);
     }
-    for (int c = tid; c < kMTile; c += 256) {
-      float h = -INFINITY;
-      if (c0 + c < nc) {
-        h = lw[c0 + c];
-        if (a.mode != 0) h += a.pot_old[cpot + c0 + c] * inv_eps;
-        h = h * kLog2e - k2 * Cn2[c0 + c];
-      }
-      hs[buf][c] = h;
+    if (tid < kMTile) {
+      const bool ok = c0 + tid < nc;
+      const int c = ok ? c0 + tid : 0;
+      s_lw = ok ? lw[c] : -INFINITY;
+      s_pot = with_pot ? a.pot_old[cpot + c] : 0.f;
+      s_n2 = Cn2[c];
     }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = sv[j];
+    if (tid < kMTile) hs[buf][tid] = (s_lw + s_pot * inv_eps) * kLog2e - k2 * s_n2;     // -inf for a padding column
   };
 
   auto block = [&](int buf, int blk) {
@@ -355,17 +386,25 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
 
   float m = -1e30f, s = 0.f;
   const int ntiles = (nc + kMTile - 1) / kMTile;
-  stage(0, 0);
+  fetch(0);
+  put(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * kMTile);
-    // this wave's two blocks: both MFMA chains are issued before the first logsumexp, so the matrix pipe works on the
-    // second block while the VALU reduces the first
+    // (the last tile fetches itself again and stores into the buffer nobody reads any more: a loop body without
+    // branches is one scheduling region, which the two sched_barriers below need)
+    fetch((t + 1 < ntiles ? t + 1 : t) * kMTile);
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's two blocks: both MFMA chains are issued before the logsumexp, so the matrix pipe works on the
+    // second block while the VALU starts on the first
     const f32x16_t acc0 = block(buf, 2 * chalf);
     const f32x16_t acc1 = block(buf, 2 * chalf + 1);
-    dense_lse_update(acc0, m, s);
-    dense_lse_update(acc1, m, s);
+    dense_lse_update(acc0, acc1, m, s);
+    // the stores (and their vmcnt wait) stay behind the logsumexp: the empty asm gives the pure arithmetic above a
+    // position in the instruction stream that the barrier can hold
+    __asm__ volatile("" : "+v"(m), "+v"(s));
+    __builtin_amdgcn_sched_barrier(0);
+    put(buf ^ 1);                // every wave finished reading that buffer before the previous barrier
     __syncthreads();
   }
   // the two lanes of a row, then the two column halves (waves w and w + 2)
@@ -390,20 +429,19 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   else a.pot_new[opot + row] = val;
 }
 
-// per-dimension mean of both point sets (D <= 16): the centre the MFMA softmin subtracts
-__global__ __launch_bounds__(256) void dense_center_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
-                                                           int M, int D, float* __restrict__ center) {
+// per-dimension SUM of a point set (D <= 16, 256 % D == 0) added into sums[D] (pre-zeroed): the centre the matrix-pipe
+// softmin subtracts is sums / (N + M) (dense_split_kernel).  (As one workgroup this took 0.34 ms of a 5.3-ms image.)
+__global__ __launch_bounds__(256) void dense_center_kernel(const float* __restrict__ p, long long n_floats, int D,
+                                                           float* __restrict__ sums) {
   __shared__ float part[256];
-  const int d = threadIdx.x % D;
   float acc = 0.f;
-  for (long long i = threadIdx.x; i < (long long)N * D; i += 256) acc += x[i];
-  for (long long i = threadIdx.x; i < (long long)M * D; i += 256) acc += y[i];
-  part[threadIdx.x] = acc;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_floats; i += (long long)gridDim.x * 256) acc += p[i];
+  part[threadIdx.x] = acc;               // thread t only ever sees dimension t % D: the stride is a multiple of D
   __syncthreads();
   if ((int)threadIdx.x < D) {
     float t = 0.f;
-    for (int j = d; j < 256; j += D) t += part[j];
-    center[d] = t / (float)(N + M);
+    for (int j = threadIdx.x; j < 256; j += D) t += part[j];
+    atomicAdd(sums + threadIdx.x, t);
   }
 }
 
@@ -501,10 +539,13 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   DenseSplit sp;
   sp.xs = splits; sp.ys = splits + (size_t)N * kSplitBytes; sp.xn2 = n2; sp.yn2 = n2 + N;
   if (use_mfma) {
-    hipLaunchKernelGGL(dense_center_kernel, dim3(1), dim3(256), 0, st, x, y, N, M, D, center);
-    hipLaunchKernelGGL(dense_split_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, N, (const float*)center,
+    if (hipMemsetAsync(center, 0, 16 * sizeof(float), st) != hipSuccess) return KD6D_ERR_LAUNCH;
+    hipLaunchKernelGGL(dense_center_kernel, dim3(64), dim3(256), 0, st, x, (long long)N * D, D, center);
+    hipLaunchKernelGGL(dense_center_kernel, dim3(64), dim3(256), 0, st, y, (long long)M * D, D, center);
+    const float inv_count = 1.0f / (float)((long long)N + M);
+    hipLaunchKernelGGL(dense_split_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, N, (const float*)center, inv_count,
                        splits, n2);
-    hipLaunchKernelGGL(dense_split_kernel, dim3((M + 255) / 256), dim3(256), 0, st, y, M, (const float*)center,
+    hipLaunchKernelGGL(dense_split_kernel, dim3((M + 255) / 256), dim3(256), 0, st, y, M, (const float*)center, inv_count,
                        splits + (size_t)N * kSplitBytes, n2 + N);
   }
   hipLaunchKernelGGL(dense_logw_kernel, dim3((N + 255) / 256), dim3(256), 0, st, alpha, la, N);

@@ -59,6 +59,10 @@ def get_argparser():
     p.add_argument("--launch", type=str, default="graph", choices=["graph", "pipeline", "eager"],
                    help="graph: replay the captured step (hipGraph); pipeline: also overlap the teacher forward of "
                         "the next batch with the student step of the current one; eager: launch kernel by kernel")
+    p.add_argument("--teacher_group", type=int, default=1,
+                   help="--launch pipeline only: run the frozen teacher over the batches of this many consecutive steps in "
+                        "one pass, cut into as many graph segments (kd6d.graph.GroupedTeacherKDStep; 2 * group batches "
+                        "of look-ahead).  1 = one teacher forward per step")
     p.add_argument("--batch_size", type=int, default=0, help="global batch; 0 = SOLVER.IMS_PER_BATCH")
     p.add_argument("--image_size", type=int, default=256, help="synthetic crop size")
     p.add_argument("--val_freq", type=int, default=0, help="validate every N steps; 0 = the backbone's default")
@@ -110,6 +114,7 @@ def build_cfgs(args):
     cfg["RUNTIME"]["SYNTHETIC"] = bool(args.synthetic)
     cfg["RUNTIME"]["SKIP_TEACHER_EVAL"] = bool(args.skip_teacher_eval)
     cfg["RUNTIME"]["LAUNCH"] = args.launch
+    cfg["RUNTIME"]["TEACHER_GROUP"] = max(1, int(args.teacher_group))
     cfg["RUNTIME"]["IMAGE_SIZE"] = int(args.image_size)
     if args.mixed_classes is not None:
         cfg["DATASETS"]["MIXED_CLASSES"] = bool(args.mixed_classes)

@@ -431,6 +431,9 @@ class PoseNet:
         self.grouping = False          # True while the reverse sweep is inside the section whose dW are collected
         self.use_wgrad_group = True
         self.wgrad_group_wgs = 0
+        # GroupedTeacherKDStep: called at layer-group boundaries of an eval-mode forward (the places where the frozen
+        # teacher's pass over several steps' batches may be cut into per-step graph segments)
+        self.cut_hook = None
         self.wgrad_group_flush = "head_end"     # or "fpn_end" (GraphedKDStep picks by launch mode)
         self.grad_hook = None           # called by backward() when the FPN + head gradients have been issued
         self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
@@ -651,8 +654,13 @@ class PoseNet:
         self._weights_dirty = False
 
     # ---- forward ---------------------------------------------------------------------------
+    def _cut(self):
+        if self.cut_hook is not None and not self.training:
+            self.cut_hook()
+
     def _backbone53(self, x, B, lv):
         x, lv = self.init_block.fwd_eval(x, B, lv) if not self.training else self.init_block.fwd_train(x, B, lv, self.tape)[:2]
+        self._cut()
         feats = []
         for units in self.stages:
             for u in units:
@@ -664,6 +672,7 @@ class PoseNet:
                                                   "in the KD step; training it is outside the hot path")
                     h, _ = u[1].fwd_eval(x, B, lv)
                     x, lv = u[2].fwd_eval(h, B, lv, residual=x)
+                self._cut()
             feats.append((x, lv))
         return feats
 
@@ -755,6 +764,7 @@ class PoseNet:
             self.outc[i].fwd(inner, B, lv, out=slot(pos))
             self.fpn_ctx[i] = (f, lv, inner)
             inner_prev = inner
+            self._cut()
         ftop, lvtop = feats[top]
         p6, _ = self.p6.fwd(ftop, B, lvtop, out=slot(len(idxs)))
         p6r = ops.eltwise(ops.ELT_RELU, p6, None, self.buf("p6_relu", p6.shape))
@@ -814,6 +824,7 @@ class PoseNet:
                     gn.fwd(raw, B, levels_all, out=y)
                 saved.append((x, raw))
                 x = y
+                self._cut()
             seg = self.store.storage(self.scales) if tname == "pose" else None
             out, _ = final.fwd(x, B, levels_all, seg_scale=seg, out_f32=True,
                                out=self.buf("%s.logits" % tname, (r, final.cout_p), torch.float32))

@@ -79,6 +79,11 @@ class GraphedKDStep:
         self.comm_stream = None
         self._split = None
 
+    @property
+    def pending_steps(self):
+        """Batches the pipeline holds that have not had their student step yet."""
+        return int(bool(self.pipeline and self.pending and self.primed))
+
     # ---- the body the reference's loop runs per iteration (train_kd.py:104-137) ----------
     def _overlap(self):
         return self.exchange == "overlap" and D.exchange_active()
@@ -334,3 +339,392 @@ class GraphedKDStep:
         out = self._replay()       # the teacher re-reads the same (last) batch: harmless, results unused
         self.primed = False        # a later call starts a new pipeline (teacher only) instead of repeating this batch
         return out
+
+
+class _GroupSide:
+    """One block of GroupedTeacherKDStep: `group` batches side by side (packed NHWC images, targets, teacher cells),
+    everything a view of ONE byte buffer."""
+    __slots__ = ("block", "nhwc", "tgts", "wf", "wi", "tk")
+
+
+class GroupedTeacherKDStep(GraphedKDStep):
+    """The pipelined step with the frozen teacher run over the batches of `group` consecutive steps AT ONCE, its pass
+    cut into `group` segments of equal device time, one beside every student step.
+
+    The teacher does not depend on the student's weights, so nothing forces it to see one batch per launch: at B = 16
+    crops most of its layers are a single partial round of tiles on 256 CUs (342 tiles of 128 x 128 on 512 slots in
+    the head towers, 8-32 tiles in stages 4-5), and the same forward over 32 / 48 images costs 83 / 72 us per image
+    instead of 104 (tools/teacher_batch_probe.py).
+
+    Three blocks of `group` batches each: LOAD (being filled, one batch per call), PASS (the teacher's input and, once
+    its last segment has run, its cells) and CURRENT (what the student trains on).  Call k = m * group + s
+        converts batch k into slot s of LOAD,
+        replays teacher segment s (its own hipGraph, on the teacher's stream) over PASS = the batches of period m - 1,
+        replays student step s (its own hipGraph [+ the optimiser]) on slot s of CURRENT = batch k - 2 * group,
+    and the last call of a period ends with CURRENT <- PASS <- LOAD (two device copies, both streams joined).  Every
+    batch still gets exactly one teacher forward and one student step.  The losses a call returns belong to batch
+    k - 2 * group (None for the first 2 * group calls); `flush()` trains one pending batch per call without consuming a
+    new one.  The teacher's segments are cut where a timed trial replay (device timestamps at every layer-group
+    boundary, PoseNet.cut_hook) says the pass has spent s / group of its time; the cut graphs are captured in ONE walk
+    through the forward, ending one capture and beginning the next at those boundaries.
+
+    (Measured on the way, 60-step runs of bench.py: the whole group pass inside the last student step's graph of a
+    period, 5110-5230 images/s at group 2-4 against 5400 for one teacher forward per step -- the steps without a teacher
+    beside them leave the device half empty and the one with it is no shorter than teacher + student back to back;
+    segment s forked and JOINED inside the graph of student step s, 5540-5660 -- every step then ends with whichever
+    branch is longer running alone; segments as graphs of their own on the teacher's stream, joined with the student's
+    stream only at the period's end, as built here: 5780-5810.)
+
+    What it needs from the caller is look-ahead only: 2 * group batches in flight instead of one."""
+
+    def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3, group=2,
+                 exchange=None):
+        super().__init__(teacher, student, optimizer, loss_weights, cfg_kd=cfg_kd, warmup=warmup, concurrent=True,
+                         pipeline=True, exchange=exchange)
+        if int(group) < 2:
+            raise ValueError("GroupedTeacherKDStep: group >= 2 (GraphedKDStep(pipeline=True) is the group of one)")
+        self.group = int(group)
+        self.g_student = self.g_teacher = None
+        import os
+        self._debug_skip_teacher = os.environ.get("KD6D_DEBUG_SKIP_TEACHER") == "1"     # timing experiments only
+        self.sides = None                 # [current, pass, load]
+        self.n_loaded = 0                 # batches in the load block
+        self.p_valid = 0                  # batches of the pass block (the teacher's input)
+        self.t_pos = 0                    # next teacher segment of the pass block
+        self.c_valid = 0                  # batches of the current block (they carry teacher cells)
+        self.c_pos = 0                    # next slot of the current block to train on
+        self.draining = False
+        self._img_big = self._tgt_big = None
+        self._geom = None
+        self.teacher_passes = 0           # completed group passes (bench.py reports them)
+        self.segment_ms = None            # the trial replay's time per segment
+
+    # `pending` of the base class, as a count
+    @property
+    def pending_steps(self):
+        return (self.c_valid - self.c_pos) + self.p_valid + self.n_loaded
+
+    @property
+    def pending(self):
+        return self.pending_steps > 0
+
+    @pending.setter
+    def pending(self, value):
+        pass
+
+    # ---- blocks ---------------------------------------------------------------------------------
+    def _build_sides(self, x, tgt):
+        from .kd_losses import CAP, TeacherKnowledge
+        T = self.group
+        B, _, H, W = x.shape
+        dev = x.device
+        snet, tnet = self.student.net, self.teacher.net
+        assert snet.dtype == tnet.dtype, "teacher and student share the converted input: same precision"
+        esz = torch.empty((), dtype=snet.dtype).element_size()
+        img_b = B * H * W * 8 * esz
+        tb = tgt.block_bytes()
+        n, nt = B * CAP, T * B * CAP
+        wf_b, wi_n = nt * 48 * 4, nt + (T * B + 3) // 4 * 4
+
+        def al(v):
+            return (v + 255) // 256 * 256
+
+        o_tgt = al(T * img_b)
+        o_wf = o_tgt + T * al(tb)
+        o_wi = o_wf + al(wf_b)
+        total = o_wi + al(wi_n * 4)
+        sides = []
+        for _ in range(3):
+            sd = _GroupSide()
+            blk = sd.block = torch.zeros(total, dtype=torch.uint8, device=dev)
+            sd.nhwc = blk[0:T * img_b].view(snet.dtype).view(T * B * H * W, 8)
+            sd.tgts = []
+            for s in range(T):
+                t = tgt.clone_static()
+                t.rebind_block(blk[o_tgt + s * al(tb):o_tgt + s * al(tb) + tb])
+                sd.tgts.append(t)
+            wf = sd.wf = blk[o_wf:o_wf + wf_b].view(torch.float32)
+            wi = sd.wi = blk[o_wi:o_wi + wi_n * 4].view(torch.int32)
+            kp, kpn = wf[0:nt * 16].view(nt, 8, 2), wf[nt * 16:nt * 32].view(nt, 8, 2)
+            sc, beta = wf[nt * 32:nt * 40].view(nt, 8), wf[nt * 40:nt * 48].view(nt, 8)
+            # the cells of slot s: a contiguous range of every slot array (they are image-major), no copies
+            sd.tk = [TeacherKnowledge(wi[nt + s * B:nt + (s + 1) * B], kp[s * n:(s + 1) * n], sc[s * n:(s + 1) * n],
+                                      wi[s * n:(s + 1) * n], kpn[s * n:(s + 1) * n], beta[s * n:(s + 1) * n], CAP, B)
+                     for s in range(T)]
+            sides.append(sd)
+        self.sides = sides
+        self._geom = (B, H, W)
+        self.images = ImageList(torch.empty(1, dtype=x.dtype, device=dev).expand(B, 3, H, W),
+                                getattr(self, "_sizes", None))                    # shape donor: the step reads `nhwc`
+        self._img_big = ImageList(torch.empty(1, dtype=x.dtype, device=dev).expand(T * B, 3, H, W), None)
+        big = object.__new__(PackedTargets)                                       # what the teacher reads of the targets
+        big.bbox_trans = torch.zeros((T * B,) + tuple(tgt.bbox_trans.shape[1:]), dtype=torch.float32, device=dev)
+        big.frame_wh = tgt.frame_wh
+        self._tgt_big = big
+
+    def _slot_rows(self, s):
+        B, H, W = self._geom
+        return slice(s * B * H * W, (s + 1) * B * H * W)
+
+    def _load_group(self, images, tgt):
+        x = images.tensors if hasattr(images, "tensors") else images
+        B, H, W = self._geom
+        assert tuple(x.shape) == (B, 3, H, W), "the captured step has a static batch shape"
+        L, s = self.sides[2], self.n_loaded
+        assert s < self.group
+        assert (tgt.mask_h, tgt.mask_w) == (L.tgts[s].mask_h, L.tgts[s].mask_w)
+        # (on the student's stream, between two replays.  On a stream of its own -- the conversion is 15 us of a chain
+        #  that bounds the step -- the step got 10-25 % SLOWER: 4640-5280 against 5780-5810 images/s at group 2-6)
+        ops.image_to_nhwc(x.contiguous(), self.student.net.dtype, 8, out=L.nhwc[self._slot_rows(s)])
+        L.tgts[s].copy_from(tgt)
+        self.n_loaded += 1
+
+    def _fill_unloaded(self):
+        """A partial load block (a drain before `group` batches arrived): the free slots repeat slot 0, so that the
+        group pass and a capture's warm-up steps see valid inputs everywhere."""
+        L = self.sides[2]
+        for s in range(self.n_loaded, self.group):
+            L.nhwc[self._slot_rows(s)].copy_(L.nhwc[self._slot_rows(0)], non_blocking=True)
+            L.tgts[s].copy_from(L.tgts[0])
+
+    def _rotate(self):
+        """Period end: CURRENT <- PASS <- LOAD.  The caller has issued every teacher segment of the pass block."""
+        main, ts = torch.cuda.current_stream(), self.teacher_stream
+        C, P, L = self.sides
+        if 0 < self.n_loaded < self.group:
+            self._fill_unloaded()
+        main.wait_stream(ts)
+        if self.p_valid:
+            C.block.copy_(P.block, non_blocking=True)
+        if self.n_loaded:
+            P.block.copy_(L.block, non_blocking=True)
+        ts.wait_stream(main)
+        self.c_valid, self.p_valid, self.n_loaded = self.p_valid, self.n_loaded, 0
+        self.c_pos = self.t_pos = 0
+
+    # ---- the teacher's pass over the pass block ----------------------------------------------------------
+    def _teacher_forward(self):
+        """Python walk through the group pass (current stream = the teacher's); its cells land in the block's flats."""
+        T = self.group
+        B = self._geom[0]
+        P, tnet = self.sides[1], self.teacher.net
+        ops.mark("teacher.start")
+        for s in range(T):
+            self._tgt_big.bbox_trans[s * B:(s + 1) * B].copy_(P.tgts[s].bbox_trans, non_blocking=True)
+        tnet.nhwc_in = P.nhwc
+        keep = getattr(self.teacher, "_teacher_flats", None)
+        self.teacher._teacher_flats = (P.wf, P.wi)
+        try:
+            self.teacher(self._img_big, targets=self._tgt_big, is_teacher=True, cfg_kd=self.cfg_kd)
+        finally:
+            tnet.nhwc_in = None
+            self.teacher._teacher_flats = keep
+        ops.mark("teacher.end")
+
+    def _time_cuts(self):
+        """Where to cut the pass: a trial graph of the whole pass with a device timestamp at every layer-group boundary
+        (PoseNet.cut_hook), replayed twice; cut k goes to the boundary closest to k / group of the total time."""
+        import ctypes
+        from ._lib import check, lib
+        T, ts, tnet = self.group, self.teacher_stream, self.teacher.net
+        tbuf = torch.zeros(1024, dtype=torch.int64, device=self.sides[1].block.device)
+        count = [0]
+
+        def stamp():
+            assert count[0] < tbuf.numel()
+            check(lib.kd6d_mark(ctypes.c_void_p(tbuf.data_ptr() + 8 * count[0]), ops._stream()), "kd6d_mark")
+            count[0] += 1
+
+        with torch.no_grad(), torch.cuda.stream(ts):
+            self._teacher_forward()                       # eager: allocates every static buffer of this batch size
+            ts.synchronize()
+            trial = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(trial, stream=ts, capture_error_mode="thread_local"):
+                stamp()
+                tnet.cut_hook = stamp
+                try:
+                    self._teacher_forward()
+                finally:
+                    tnet.cut_hook = None
+                stamp()
+            trial.replay(); trial.replay()
+            ts.synchronize()
+        t = tbuf[:count[0]].cpu().tolist()
+        rel = [(v - t[0]) * 1e-5 for v in t[1:]]          # ms after the start; rel[i] = end of layer group i, rel[-1] = end
+        total, nhook = rel[-1], len(rel) - 1
+        assert nhook >= T - 1, "the teacher's forward passes fewer cut points than segments"
+        cuts, last = [], -1
+        for k in range(1, T):
+            cand = range(last + 1, nhook - (T - 1 - k))
+            i = min(cand, key=lambda j: abs(rel[j] - k * total / T))
+            cuts.append(i); last = i
+        edges = [0.0] + [rel[i] for i in cuts] + [total]
+        self.segment_ms = [edges[i + 1] - edges[i] for i in range(T)]
+        del trial
+        return cuts
+
+    def _capture_teacher(self):
+        """The pass over the pass block as `group` graphs, captured in ONE walk through the forward: the hook ends the
+        running capture at a cut and begins the next graph's."""
+        T, ts, tnet = self.group, self.teacher_stream, self.teacher.net
+        torch.cuda.synchronize()
+        cuts = self._time_cuts()
+        graphs = [torch.cuda.CUDAGraph() for _ in range(T)]
+        pool = torch.cuda.graph_pool_handle()
+        state = {"hook": 0, "g": 0}
+
+        def switch():
+            g = state["g"]
+            if g < T - 1 and state["hook"] == cuts[g]:
+                graphs[g].capture_end()
+                state["g"] = g + 1
+                graphs[g + 1].capture_begin(pool=pool, capture_error_mode="thread_local")
+            state["hook"] += 1
+
+        torch.cuda.synchronize()
+        with torch.no_grad(), torch.cuda.stream(ts):
+            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+            tnet.cut_hook = switch
+            try:
+                self._teacher_forward()
+            finally:
+                tnet.cut_hook = None
+                graphs[state["g"]].capture_end()
+        assert state["g"] == T - 1, "the teacher's forward passed fewer cut points than segments"
+        torch.cuda.synchronize()
+        self.g_teacher = graphs
+
+    def _teacher_segments(self, upto):
+        """Issue the pass block's segments t_pos .. upto - 1 on the teacher's stream."""
+        if self.p_valid == 0 or self.t_pos >= upto:
+            return
+        if self.g_teacher is None:
+            self._capture_teacher()
+        with torch.cuda.stream(self.teacher_stream):
+            while self.t_pos < upto:
+                if not self._debug_skip_teacher:
+                    self.g_teacher[self.t_pos].replay()
+                self.t_pos += 1
+                if self.t_pos == self.group:
+                    self.teacher_passes += 1
+
+    # ---- the student's step on one slot of the current block ----------------------------------------------
+    def _student_body(self, s):
+        C = self.sides[0]
+        ops.mark("step.start")
+        self.tgt, self.t_cur = C.tgts[s], C.tk[s]
+        self._nhwc = (C.nhwc[self._slot_rows(s)], None)
+        losses = self._student_step(self.t_cur)
+        ops.mark("step.end")
+        return losses
+
+    def _snapshot(self):
+        st, opt = self.student.net.store, self.opt
+        return dict(params=st.params.clone(), bufs=st.bufs.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(),
+                    nbt=self.student._nbt.clone(), steps=opt.steps, sc=getattr(opt, "_step_count", None))
+
+    def _restore(self, snap):
+        st, opt = self.student.net.store, self.opt
+        st.params.copy_(snap["params"]); st.bufs.copy_(snap["bufs"])
+        opt.exp_avg.copy_(snap["m"]); opt.exp_avg_sq.copy_(snap["v"])
+        self.student._nbt.copy_(snap["nbt"])
+        if st.shadow is not None:
+            st.refresh_shadow()
+        opt.steps = snap["steps"]
+        if snap["sc"] is not None:
+            opt._step_count = snap["sc"]
+
+    def _capture(self):
+        """The `group` student graphs (one per slot of the current block; the blocks are only read)."""
+        T = self.group
+        self.student._defer_allreduce = True
+        torch.cuda.synchronize()
+        snap = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                        # eager warm-up: allocates every static buffer
+            for _ in range(self.warmup):
+                for s in range(T):
+                    self._student_body(s)
+                    self._exchange()
+                    self.opt.advance()
+                    self.opt.launch(device_schedule=True)
+                    self._count_opt_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graphs_per_step = 2 if (D.exchange_active() and not self._overlap()) else 1
+        self.g_student, pool = [], None
+        for s in range(T):
+            g = torch.cuda.CUDAGraph()
+            kw = {} if pool is None else {"pool": pool}
+            with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
+                self.losses = self._student_body(s)
+                if self.graphs_per_step == 1:
+                    self.opt.launch(device_schedule=True)
+            pool = g.pool()
+            self.g_student.append(g)
+        self.g_step = self.g_student[0]
+        if self.graphs_per_step == 2:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=pool, capture_error_mode="thread_local"):
+                self.opt.launch(device_schedule=True)
+        self._restore(snap)
+
+    def _replay_student(self, s):
+        if self.graphs_per_step == 1:
+            self.opt.advance()
+            self.g_student[s].replay()
+        else:
+            self.g_student[s].replay()
+            self._exchange()
+            self.opt.advance()
+            self.g_opt.replay()
+        self._count_opt_step()
+        for _, bn in self.student.net.bns:
+            bn.fold = None
+        return self.losses
+
+    # ---- one tick of the pipeline -------------------------------------------------------------------------
+    def _tick(self, drain):
+        T = self.group
+        if drain:
+            while self.c_pos >= self.c_valid:      # nothing trainable: finish the teacher on the pass block, rotate
+                self._teacher_segments(T)
+                self._rotate()
+        out = None
+        if self.c_pos < self.c_valid:
+            s = self.c_pos
+            if self.g_student is None:             # (capture before this step's teacher segment goes out)
+                self._capture()
+            self._teacher_segments(s + 1)          # segment s beside student step s
+            out = self._replay_student(s)
+            self.c_pos += 1
+        if not drain and self.n_loaded == T:       # period end
+            self._teacher_segments(T)
+            self._rotate()
+        return out
+
+    # ---- public -------------------------------------------------------------------------------------
+    def __call__(self, images, tgt):
+        """One call = one batch in.  Returns the (device, static) loss scalars of batch k - 2 * group, None while the
+        pipeline fills (the first 2 * group calls)."""
+        if not isinstance(tgt, PackedTargets):
+            tgt = PackedTargets(tgt, self.student.net.device)
+        if self.sides is None:
+            self._sizes = getattr(images, "sizes", None)
+            self._build_sides(images.tensors if hasattr(images, "tensors") else images, tgt)
+        if self.draining:
+            if self.pending_steps > 0:
+                raise RuntimeError("GroupedTeacherKDStep: flush() the %d pending batches before feeding new ones"
+                                   % self.pending_steps)
+            self.draining = False
+        self._load_group(images, tgt)
+        return self._tick(False)
+
+    def flush(self):
+        """Train on ONE batch that is still waiting for its student step, without consuming a new one; None when
+        nothing is pending.  (Call until it returns None to drain the pipeline; a later __call__ starts a new one.)"""
+        if self.sides is None or self.pending_steps == 0:
+            return None
+        self.draining = True
+        return self._tick(True)

@@ -214,9 +214,17 @@ def test_full_frame_640x480_pipelined_graph_vs_oracle(gpu_device, precision):
     _pipelined_graph_vs_oracle(gpu_device, precision, "darknet_tiny_h", False, full=True)
 
 
-def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_benchmark_config_grouped_teacher_vs_oracle(gpu_device, precision):
+    """The launch mode bench.py times by default -- GroupedTeacherKDStep(group=2): the teacher over the 32 images of two
+    steps in one pass, cut into two graph segments, one beside each student step -- on BASELINE config 2 at full size,
+    against the same oracle steps with the same bounds as the one-batch-per-pass pipeline above."""
+    _pipelined_graph_vs_oracle(gpu_device, precision, "darknet_tiny_h", False, full=False, group=2)
+
+
+def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1):
     from kd6d import ops
-    from kd6d.graph import GraphedKDStep
+    from kd6d.graph import GraphedKDStep, GroupedTeacherKDStep
     from kd6d.kd_losses import PackedTargets
     from kd6d.libs.poses import ImageList
     from kd6d.optim import FusedClipAdamW
@@ -277,10 +285,16 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
         del twins
         torch.cuda.empty_cache()
 
-    gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=True)
     p0 = student.net.store.params.detach().cpu().clone()
-    assert gs(*batches[0]) is None                          # priming call: teacher(0)
-    ld = gs(*batches[1])                                    # teacher(1) beside the student step on batch 0 (captures)
+    if group == 1:
+        gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=True)
+        assert gs(*batches[0]) is None                      # priming call: teacher(0)
+        ld = gs(*batches[1])                                # teacher(1) beside the student step on batch 0 (captures)
+    else:
+        gs = GroupedTeacherKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=group)
+        for i in range(2 * group):                          # two periods fill the pipeline: batches 0, 1, 0, 1, ...
+            assert gs(*batches[i % 2]) is None
+        ld = gs(*batches[0])                                # the student step on batch 0 (captures)
     torch.cuda.synchronize()
     got1 = {k: float(v) for k, v in ld.items()}
     gn1 = float(opt.grad_norm())
@@ -331,7 +345,8 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full):
     if not full:
         rep.update({"d2_" + k: abs(got2[k] - res2[k]) / max(abs(res2[k]), 1e-6) for k in got2})
     rep["barrier_timeouts"] = int(ops.lib.kd6d_barrier_timeouts())
-    _record("%s_%s" % (arch + ("_mixed13" if mixed else "") + ("_full640" if full else ""), precision), rep)
+    _record("%s_%s" % (arch + ("_mixed13" if mixed else "") + ("_full640" if full else "") + ("_group%d" % group if group > 1 else ""),
+                       precision), rep)
     print("[fullsize %s %s] %s" % (arch, precision, json.dumps(rep, default=str)))
 
     assert rep["barrier_timeouts"] == 0

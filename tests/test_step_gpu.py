@@ -464,6 +464,76 @@ def test_pipeline_restarts_after_flush(gpu_device):
     assert got[2] > 0, "the KD term must be active in this test"
 
 
+@pytest.mark.parametrize("group", [2, 3])
+def test_grouped_teacher_matches_sequential_steps(gpu_device, group):
+    """GroupedTeacherKDStep (the teacher over the batches of `group` steps in one pass, cut into `group` graph segments,
+    kd6d/graph.py) trains exactly like the strictly sequential replayed step: 10 batches in, 2 * group priming calls that
+    return None, then the loss of batch k - 2 * group per call, flush() once per batch still pending (the last period is
+    a partial one: 10 is not a multiple of 3; group 2 drains from a period boundary) and None afterwards; every step's three losses and the final parameters agree with
+    GraphedKDStep(pipeline=False) over the same batches (fp32; the teacher's layers tile 2-3x the rows differently, so
+    its cells agree to rounding, not bitwise).  A call after the drain starts a new pipeline."""
+    from kd6d.graph import GraphedKDStep, GroupedTeacherKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import make_batch
+    dev = gpu_device
+    B, crop, n = 2, 64, 10
+    batches = []
+    for i in range(n):
+        images, targets = make_batch(B, 40 + i, crop=crop)
+        batches.append((ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)))
+    rows = B * sum((crop // 8 // 2 ** i) ** 2 for i in range(4))
+    keys = torch.rand(rows, generator=torch.Generator().manual_seed(3)).to(dev)
+    names = ("loss_cls", "loss_reg", "loss_kd")
+
+    def make(grouped):
+        teacher = build("darknet53", "fp32", 2, dev, [1.0] + [-6.0] * 14).eval()
+        student = build("darknet_tiny_h", "fp32", 1, dev).train()
+        student._debug_keys = keys
+        opt = FusedClipAdamW(student, lr=1e-4)
+        gs = (GroupedTeacherKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=group) if grouped
+              else GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=False))
+        return gs, student, opt
+
+    gs, student, opt = make(False)
+    want = []
+    for b in batches:
+        ld = gs(*b)
+        want.append([float(ld[k]) for k in names])
+    p_want = student.net.store.params.detach().clone()
+    assert opt.steps == n
+
+    gs, student, opt = make(True)
+    got = []
+    for i, b in enumerate(batches):
+        ld = gs(*b)
+        assert (ld is None) == (i < 2 * group)
+        if ld is not None:
+            got.append([float(ld[k]) for k in names])
+    assert opt.steps == n - 2 * group and gs.pending_steps == 2 * group
+    with pytest.raises(RuntimeError):
+        # a partly drained pipeline takes no new batches
+        gs.flush(); got.append([float(gs.losses[k]) for k in names]); gs(*batches[0])
+    while True:
+        ld = gs.flush()
+        if ld is None:
+            break
+        got.append([float(ld[k]) for k in names])
+    assert opt.steps == n and len(got) == n and gs.pending_steps == 0 and not gs.pending
+    # the first steps agree to rounding; ten AdamW steps on, the atomic-order noise of either run has grown to 0.5-1 %
+    # of a loss (two runs of the SEQUENTIAL step differ by as much: lr * sign(g) flips where g is near zero)
+    np.testing.assert_allclose(np.array(got[:3]), np.array(want[:3]), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=3e-2, atol=1e-6)
+    assert np.array(want)[:, 2].min() > 0, "the KD term must be active in this test"
+    d = (student.net.store.params.detach() - p_want).abs()
+    assert float(d.max()) <= 2.1e-3 and float(d.mean()) <= 5e-5, (float(d.max()), float(d.mean()))   # 10 steps of lr 1e-4: a
+    # parameter moves by <= 1e-3, so two runs are at most 2e-3 apart -- where the sign of a near-zero gradient differs
+    assert gs.teacher_passes >= n // group and len(gs.segment_ms) == group
+    assert gs(*batches[0]) is None and opt.steps == n      # a new pipeline: loading only
+    assert gs.pending_steps == 1
+
+
 def test_replayed_step_draws_new_sampling_keys(gpu_device):
     """Without pinned keys the replayed step draws its SSC sampling keys on the device from (seed, step counter, cell):
     every replay sees new keys in [0, 1), the same seed reproduces the sequence, and the step stays finite."""

@@ -165,9 +165,14 @@ if __name__ == "__main__":
     launch = cfg["RUNTIME"].get("LAUNCH", "graph")
     gstep = None
     if launch != "eager":
-        from kd6d.graph import GraphedKDStep
-        gstep = GraphedKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd,
-                              pipeline=(launch == "pipeline"))
+        from kd6d.graph import GraphedKDStep, GroupedTeacherKDStep
+        group = int(cfg["RUNTIME"].get("TEACHER_GROUP", 1))
+        if launch == "pipeline" and group > 1:
+            # the teacher over the batches of `group` steps in one pass (2 * group batches in flight)
+            gstep = GroupedTeacherKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd, group=group)
+        else:
+            gstep = GraphedKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd,
+                                  pipeline=(launch == "pipeline"))
     MAX_ITER = cfg["SOLVER"]["MAX_ITER"]
     pipelined = gstep is not None and gstep.pipeline
     for idx, (images, targets, _) in enumerate(train_loader):
@@ -179,9 +184,10 @@ if __name__ == "__main__":
             break
         if gstep is not None:
             # the same iteration body (train_kd.py:104-140 of the reference), captured once and replayed.  Pipelined:
-            # call k runs the teacher on batch k beside the student step on batch k-1, so the LAST step is the
-            # flush of the pending batch (no new batch is consumed for it): exactly MAX_ITER optimiser steps
-            if pipelined and total_steps == MAX_ITER - 1 and gstep.pending:
+            # call k runs the teacher on batch k beside the student step on batch k-1 (grouped: k - 2 * group), so the
+            # LAST steps are flushes of the pending batches (no new batch is consumed for them): exactly MAX_ITER
+            # optimiser steps
+            if pipelined and gstep.pending_steps > 0 and total_steps + gstep.pending_steps >= MAX_ITER:
                 loss_dict = gstep.flush()
             else:
                 loss_dict = gstep(images, targets)
