@@ -10,6 +10,12 @@ One step = teacher (Darknet-53, frozen, eval) forward + teacher cell selection +
 synthetic LINEMOD-shaped batch (640x480 frame geometry, 256x256 DZI crops: what the reference
 actually feeds the network), B = 16 images per GPU, inputs resident in HBM.
 
+Default launch mode (--teacher-group 2, kd6d.graph.GroupedTeacherKDStep): the frozen teacher runs over the 32 images of
+two consecutive steps in one pass, cut into two hipGraph segments of equal device time, one replayed on the teacher's
+stream beside each student step; every batch still gets exactly one teacher forward and one student step.  The timed
+region is aligned so that it ENDS with a completed pass: it holds ceil(K / group) passes, i.e. >= K * B images through
+the teacher (`config.teacher_images_in_timed_region`).  --teacher-group 1 = one teacher forward per step (rounds 1-2).
+
 `python bench.py --gpus N` without WORLD_SIZE in the environment launches its own N ranks (one child process per
 GPU, started before this process makes any GPU call; rank 0's line is passed through, a failing rank fails the run).
 
@@ -26,8 +32,8 @@ The single JSON line carries, besides the contract fields:
                   against the imported reference) timed on this host's cores, rank 0, N=1 only.
   secondary    -- (N=1, default workload only) 20-step timings of the other BASELINE configurations, each run by this
                   same script in a child process AFTER the headline's timed region: config 4's per-GPU shard
-                  (--workload linemod13), full 480x640 frames (--frame full640), strictly sequential steps
-                  (--no-pipeline) and the dense 16-D OT of config 5 (--workload dense16d).  The headline does not
+                  (--workload linemod13), full 480x640 frames (--frame full640), one teacher forward per step
+                  (--teacher-group 1), strictly sequential steps (--no-pipeline) and the dense 16-D OT of config 5 (--workload dense16d).  The headline does not
                   depend on them: a failing child is reported inside its entry.
 """
 import argparse
@@ -85,9 +91,15 @@ def parse():
     p.add_argument("--no-launch-events", action="store_true",
                    help="skip the eagerly launched, HIP-event-instrumented steps behind roofline.eager_launch_events")
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
-    p.add_argument("--teacher-group", type=int, default=1,
+    p.add_argument("--teacher-group", type=int, default=0,
                    help="pipelined launch only: run the frozen teacher over the batches of this many consecutive steps at "
-                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step")
+                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step; 0 (default) = 2 on one "
+                        "rank, 1 when a gradient exchange is active (measured with the one-rank RCCL rehearsal: the "
+                        "all-reduce beside a free-running teacher stream costs more than the grouping gains, 4730-4800 "
+                        "against 5340-5460 images/s)")
+    p.add_argument("--debug-skip-teacher", type=int, default=0,
+                   help="timing experiment, INVALID as a result (reported as such): 1 = replay no teacher segment, 2 = every "
+                        "second one -- what the student's steps cost without / with half of the teacher beside them")
     p.add_argument("--no-pipeline", action="store_true",
                    help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
     p.add_argument("--cpu-steps", type=int, default=4)
@@ -303,6 +315,8 @@ def main():
         batches.append((images.to(dev), PackedTargets(targets, dev)))
 
     from kd6d.graph import GraphedKDStep
+    if args.teacher_group == 0:
+        args.teacher_group = 1 if use_pg else 2
     if args.no_graph:
         gstep = None
     else:
@@ -312,6 +326,8 @@ def main():
         else:
             gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
     group = getattr(gstep, "group", 1)
+    if args.debug_skip_teacher and group > 1:
+        gstep._debug_skip_teacher = args.debug_skip_teacher
     if args.timeline and gstep is not None:
         ops.marks_begin(dev)                     # before the capture: the markers become graph nodes
     n_prime = 0
@@ -473,7 +489,7 @@ def main():
                           "teacher_passes_in_timed_region": passes_timed if group > 1 else args.steps,
                           "teacher_images_in_timed_region": (passes_timed * group * B) if group > 1 else args.steps * B,
                           "weights": "random-init (seeded), teacher cls bias set so ~10 cells/img pass 0.1"},
-               "losses_last_step": losses, "finite": finite, "barrier_timeouts": barrier_timeouts,
+               "losses_last_step": losses, "finite": finite and not args.debug_skip_teacher, "barrier_timeouts": barrier_timeouts,
                "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
                "host_issue_ms_idle_gpu": min(t_issue) * 1e3,
                "roofline": roof}
@@ -482,7 +498,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, B, full)
         if pinned:
             out["config"]["host_cpus_per_rank"] = pinned
-        default_run = (args.workload == "ape" and not full and not args.no_pipeline and not args.no_graph
+        default_run = (args.workload == "ape" and not full and not args.no_pipeline and not args.no_graph and args.teacher_group == 2
                        and args.student == "darknet_tiny_h" and args.precision == "bf16" and not args.opt)
         if world == 1 and default_run and not args.no_secondary:
             out["secondary"] = secondary_runs(args)
@@ -600,6 +616,8 @@ def bench_dense(args, out_fd):
 SECONDARY = [          # (name, BASELINE.json config it stands for, extra flags)
     ("linemod13", "config 4 per-GPU shard: 13 LINEMOD classes mixed per batch, darknet53 -> darknet_tiny", ["--workload", "linemod13"]),
     ("full640", "S640 variant of config 2: (16,3,480,640) full frames", ["--frame", "full640"]),
+    ("teacher_group1", "config 2, one teacher forward per step beside the previous batch's student step (the launch mode of "
+                       "rounds 1-2)", ["--teacher-group", "1"]),
     ("no_pipeline", "config 2, strictly sequential steps (teacher and student of the SAME batch in one step)", ["--no-pipeline"]),
     ("dense16d", "config 5: dense 16-D OT over a 128x128 cell grid", ["--workload", "dense16d"]),
 ]

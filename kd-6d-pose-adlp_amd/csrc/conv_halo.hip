@@ -374,7 +374,10 @@ bool dispatch_halo(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st)
   if (kd6d_opt(KD6D_OPT_CONV_HALO_PAIRING) != 0 && halo <= 33) {
     // (96 x 128 tiles for the 342-tile tower shape -- 456 tiles on 512 slots instead of 86 CUs carrying two tiles of 128 x
     //  128 and 170 one -- were built and measured in round 3: 5064-5099 against 5184-5192 images/s, interleaved; removed)
-    if (pick == 3 || pick == 6) pick = 12;
+    // (256 x 128, one workgroup per CU, is what the counts above pick from ~40 000 rows on -- the teacher's towers over
+    //  the 32 images of a grouped pass: 2.25 us per image against 1.75 for the twins, 1.91 for 192 x 128; tools/bench_conv.py
+    //  --batch 32 --opt conv.halo=N)
+    if (pick == 3 || pick == 6 || pick == 1) pick = 12;
     else if (pick == 4) pick = 13;
     else if (pick == 9) pick = 14;
     else if (pick == 5) pick = 15;

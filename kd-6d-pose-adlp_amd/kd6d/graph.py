@@ -379,14 +379,14 @@ class GroupedTeacherKDStep(GraphedKDStep):
 
     def __init__(self, teacher, student, optimizer, loss_weights=(0.1, 1.0, 5.0), cfg_kd=None, warmup=3, group=2,
                  exchange=None):
-        super().__init__(teacher, student, optimizer, loss_weights, cfg_kd=cfg_kd, warmup=warmup, concurrent=True,
-                         pipeline=True, exchange=exchange)
         if int(group) < 2:
             raise ValueError("GroupedTeacherKDStep: group >= 2 (GraphedKDStep(pipeline=True) is the group of one)")
+        super().__init__(teacher, student, optimizer, loss_weights, cfg_kd=cfg_kd, warmup=warmup, concurrent=True,
+                         pipeline=True, exchange=exchange)
         self.group = int(group)
         self.g_student = self.g_teacher = None
-        import os
-        self._debug_skip_teacher = os.environ.get("KD6D_DEBUG_SKIP_TEACHER") == "1"     # timing experiments only
+        self._debug_skip_teacher = 0      # timing experiments only (bench.py --debug-skip-teacher): 1 = no teacher segment
+        # is replayed, 2 = every second one
         self.sides = None                 # [current, pass, load]
         self.n_loaded = 0                 # batches in the load block
         self.p_valid = 0                  # batches of the pass block (the teacher's input)
@@ -417,6 +417,12 @@ class GroupedTeacherKDStep(GraphedKDStep):
         from .kd_losses import CAP, TeacherKnowledge
         T = self.group
         B, _, H, W = x.shape
+        if T * B * H * W >= 1 << 24:
+            # the convolution entry points take < 2^24 rows per launch (kd6d_conv2d_fwd: "grid too large"); the group
+            # pass's first layer has group * B * H * W of them
+            raise ValueError("GroupedTeacherKDStep: group %d x %d images of %dx%d = %d input pixels per teacher pass, the "
+                             "convolution launches take < 2^24 rows: use group <= %d"
+                             % (T, B, H, W, T * B * H * W, ((1 << 24) - 1) // (B * H * W)))
         dev = x.device
         snet, tnet = self.student.net, self.teacher.net
         assert snet.dtype == tnet.dtype, "teacher and student share the converted input: same precision"
@@ -467,17 +473,20 @@ class GroupedTeacherKDStep(GraphedKDStep):
         return slice(s * B * H * W, (s + 1) * B * H * W)
 
     def _load_group(self, images, tgt):
+        assert self.n_loaded < self.group
+        self._load_device(images, tgt, self.n_loaded)
+        self.n_loaded += 1
+
+    def _load_device(self, images, tgt, s):
         x = images.tensors if hasattr(images, "tensors") else images
         B, H, W = self._geom
         assert tuple(x.shape) == (B, 3, H, W), "the captured step has a static batch shape"
-        L, s = self.sides[2], self.n_loaded
-        assert s < self.group
+        L = self.sides[2]
         assert (tgt.mask_h, tgt.mask_w) == (L.tgts[s].mask_h, L.tgts[s].mask_w)
         # (on the student's stream, between two replays.  On a stream of its own -- the conversion is 15 us of a chain
         #  that bounds the step -- the step got 10-25 % SLOWER: 4640-5280 against 5780-5810 images/s at group 2-6)
         ops.image_to_nhwc(x.contiguous(), self.student.net.dtype, 8, out=L.nhwc[self._slot_rows(s)])
         L.tgts[s].copy_from(tgt)
-        self.n_loaded += 1
 
     def _fill_unloaded(self):
         """A partial load block (a drain before `group` batches arrived): the free slots repeat slot 0, so that the
@@ -489,18 +498,21 @@ class GroupedTeacherKDStep(GraphedKDStep):
 
     def _rotate(self):
         """Period end: CURRENT <- PASS <- LOAD.  The caller has issued every teacher segment of the pass block."""
-        main, ts = torch.cuda.current_stream(), self.teacher_stream
-        C, P, L = self.sides
-        if 0 < self.n_loaded < self.group:
-            self._fill_unloaded()
-        main.wait_stream(ts)
-        if self.p_valid:
-            C.block.copy_(P.block, non_blocking=True)
-        if self.n_loaded:
-            P.block.copy_(L.block, non_blocking=True)
-        ts.wait_stream(main)
+        self._rotate_device(bool(self.p_valid), self.n_loaded)
         self.c_valid, self.p_valid, self.n_loaded = self.p_valid, self.n_loaded, 0
         self.c_pos = self.t_pos = 0
+
+    def _rotate_device(self, pass_valid, n_loaded):
+        main, ts = torch.cuda.current_stream(), self.teacher_stream
+        C, P, L = self.sides
+        if 0 < n_loaded < self.group:
+            self._fill_unloaded()
+        main.wait_stream(ts)
+        if pass_valid:
+            C.block.copy_(P.block, non_blocking=True)
+        if n_loaded:
+            P.block.copy_(L.block, non_blocking=True)
+        ts.wait_stream(main)
 
     # ---- the teacher's pass over the pass block ----------------------------------------------------------
     def _teacher_forward(self):
@@ -596,17 +608,19 @@ class GroupedTeacherKDStep(GraphedKDStep):
 
     def _teacher_segments(self, upto):
         """Issue the pass block's segments t_pos .. upto - 1 on the teacher's stream."""
-        if self.p_valid == 0 or self.t_pos >= upto:
-            return
+        while self.p_valid and self.t_pos < upto:
+            self._replay_teacher_segment(self.t_pos)
+            self.t_pos += 1
+            if self.t_pos == self.group:
+                self.teacher_passes += 1
+
+    def _replay_teacher_segment(self, i):
         if self.g_teacher is None:
             self._capture_teacher()
+        if self._debug_skip_teacher == 1 or (self._debug_skip_teacher == 2 and i % 2 == 1):
+            return
         with torch.cuda.stream(self.teacher_stream):
-            while self.t_pos < upto:
-                if not self._debug_skip_teacher:
-                    self.g_teacher[self.t_pos].replay()
-                self.t_pos += 1
-                if self.t_pos == self.group:
-                    self.teacher_passes += 1
+            self.g_teacher[i].replay()
 
     # ---- the student's step on one slot of the current block ----------------------------------------------
     def _student_body(self, s):
@@ -670,6 +684,10 @@ class GroupedTeacherKDStep(GraphedKDStep):
                 self.opt.launch(device_schedule=True)
         self._restore(snap)
 
+    def _ensure_captured(self):
+        if self.g_student is None:
+            self._capture()
+
     def _replay_student(self, s):
         if self.graphs_per_step == 1:
             self.opt.advance()
@@ -694,8 +712,7 @@ class GroupedTeacherKDStep(GraphedKDStep):
         out = None
         if self.c_pos < self.c_valid:
             s = self.c_pos
-            if self.g_student is None:             # (capture before this step's teacher segment goes out)
-                self._capture()
+            self._ensure_captured()                # (before this step's teacher segment goes out)
             self._teacher_segments(s + 1)          # segment s beside student step s
             out = self._replay_student(s)
             self.c_pos += 1
@@ -708,11 +725,7 @@ class GroupedTeacherKDStep(GraphedKDStep):
     def __call__(self, images, tgt):
         """One call = one batch in.  Returns the (device, static) loss scalars of batch k - 2 * group, None while the
         pipeline fills (the first 2 * group calls)."""
-        if not isinstance(tgt, PackedTargets):
-            tgt = PackedTargets(tgt, self.student.net.device)
-        if self.sides is None:
-            self._sizes = getattr(images, "sizes", None)
-            self._build_sides(images.tensors if hasattr(images, "tensors") else images, tgt)
+        tgt = self._prepare(images, tgt)
         if self.draining:
             if self.pending_steps > 0:
                 raise RuntimeError("GroupedTeacherKDStep: flush() the %d pending batches before feeding new ones"
@@ -721,10 +734,18 @@ class GroupedTeacherKDStep(GraphedKDStep):
         self._load_group(images, tgt)
         return self._tick(False)
 
+    def _prepare(self, images, tgt):
+        if not isinstance(tgt, PackedTargets):
+            tgt = PackedTargets(tgt, self.student.net.device)
+        if self.sides is None:
+            self._sizes = getattr(images, "sizes", None)
+            self._build_sides(images.tensors if hasattr(images, "tensors") else images, tgt)
+        return tgt
+
     def flush(self):
         """Train on ONE batch that is still waiting for its student step, without consuming a new one; None when
         nothing is pending.  (Call until it returns None to drain the pipeline; a later __call__ starts a new one.)"""
-        if self.sides is None or self.pending_steps == 0:
+        if self.pending_steps == 0:
             return None
         self.draining = True
         return self._tick(True)
