@@ -10,9 +10,9 @@ One step = teacher (Darknet-53, frozen, eval) forward + teacher cell selection +
 synthetic LINEMOD-shaped batch (640x480 frame geometry, 256x256 DZI crops: what the reference
 actually feeds the network), B = 16 images per GPU, inputs resident in HBM.
 
-Default launch mode (--teacher-group 2, kd6d.graph.GroupedTeacherKDStep): the frozen teacher runs over the 32 images of
-two consecutive steps in one pass, cut into two hipGraph segments of equal device time, one replayed on the teacher's
-stream beside each student step; every batch still gets exactly one teacher forward and one student step.  The timed
+Default launch mode on one rank (--teacher-group 3, kd6d.graph.GroupedTeacherKDStep): the frozen teacher runs over the 48
+images of three consecutive steps in one pass, cut into three hipGraph segments of equal device time, one replayed on the
+teacher's stream beside each student step; every batch still gets exactly one teacher forward and one student step.  The timed
 region is aligned so that it ENDS with a completed pass: it holds ceil(K / group) passes, i.e. >= K * B images through
 the teacher (`config.teacher_images_in_timed_region`).  --teacher-group 1 = one teacher forward per step (rounds 1-2).
 
@@ -93,13 +93,17 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--teacher-group", type=int, default=0,
                    help="pipelined launch only: run the frozen teacher over the batches of this many consecutive steps at "
-                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step; 0 (default) = 2 on one "
+                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step; 0 (default) = 3 on one "
                         "rank, 1 when a gradient exchange is active (measured with the one-rank RCCL rehearsal: the "
                         "all-reduce beside a free-running teacher stream costs more than the grouping gains, 4730-4800 "
                         "against 5340-5460 images/s)")
     p.add_argument("--debug-skip-teacher", type=int, default=0,
                    help="timing experiment, INVALID as a result (reported as such): 1 = replay no teacher segment, 2 = every "
                         "second one -- what the student's steps cost without / with half of the teacher beside them")
+    p.add_argument("--tune", action="append", default=[],
+                   help="schedule experiment, name=value: budget_div (CUs / this = the weight gradients' split-K budget), "
+                        "group_wgs (workgroups of the grouped weight gradient), group_flush (head_end|fpn_end), streams "
+                        "(weight-gradient side streams)")
     p.add_argument("--no-pipeline", action="store_true",
                    help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
     p.add_argument("--cpu-steps", type=int, default=4)
@@ -315,8 +319,11 @@ def main():
         batches.append((images.to(dev), PackedTargets(targets, dev)))
 
     from kd6d.graph import GraphedKDStep
+    tune = dict(kv.split("=") for kv in args.tune)
+    if "streams" in tune:
+        GraphedKDStep.WGRAD_STREAMS = int(tune["streams"])
     if args.teacher_group == 0:
-        args.teacher_group = 1 if use_pg else 2
+        args.teacher_group = 1 if use_pg else 3
     if args.no_graph:
         gstep = None
     else:
@@ -326,6 +333,13 @@ def main():
         else:
             gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
     group = getattr(gstep, "group", 1)
+    if gstep is not None:
+        if "budget_div" in tune:
+            student.net.wgrad_cu_budget = int(ops.device_cu_count() / float(tune["budget_div"]))
+        if "group_wgs" in tune:
+            student.net.wgrad_group_wgs = int(tune["group_wgs"])
+        if "group_flush" in tune:
+            student.net.wgrad_group_flush = tune["group_flush"]
     if args.debug_skip_teacher and group > 1:
         gstep._debug_skip_teacher = args.debug_skip_teacher
     if args.timeline and gstep is not None:
@@ -498,8 +512,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, B, full)
         if pinned:
             out["config"]["host_cpus_per_rank"] = pinned
-        default_run = (args.workload == "ape" and not full and not args.no_pipeline and not args.no_graph and args.teacher_group == 2
-                       and args.student == "darknet_tiny_h" and args.precision == "bf16" and not args.opt)
+        default_run = (args.workload == "ape" and not full and not args.no_pipeline and not args.no_graph and args.teacher_group == 3
+                       and args.student == "darknet_tiny_h" and args.precision == "bf16" and not args.opt and not args.tune)
         if world == 1 and default_run and not args.no_secondary:
             out["secondary"] = secondary_runs(args)
     if use_pg:

@@ -384,6 +384,14 @@ class GroupedTeacherKDStep(GraphedKDStep):
         super().__init__(teacher, student, optimizer, loss_weights, cfg_kd=cfg_kd, warmup=warmup, concurrent=True,
                          pipeline=True, exchange=exchange)
         self.group = int(group)
+        # the student's graphs have no teacher branch of their own and the teacher's segments run beside ALL of a step,
+        # not its first 60 %: the weight-gradient settings of the strictly sequential step win here too (100-step runs,
+        # interleaved, group 2: 5950-5980 images/s with the pipelined settings, 6200-6220 with two workgroups per CU for
+        # the grouped launch and its flush behind the FPN sweep; CUs / 4 per side-stream launch: +-0)
+        snet = student.net
+        snet.wgrad_cu_budget = int(ops.device_cu_count() / self.WGRAD_BUDGET_DIV[False])
+        snet.wgrad_group_wgs = 2 * ops.device_cu_count()
+        snet.wgrad_group_flush = "fpn_end"
         self.g_student = self.g_teacher = None
         self._debug_skip_teacher = 0      # timing experiments only (bench.py --debug-skip-teacher): 1 = no teacher segment
         # is replayed, 2 = every second one

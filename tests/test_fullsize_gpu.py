@@ -216,10 +216,10 @@ def test_full_frame_640x480_pipelined_graph_vs_oracle(gpu_device, precision):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_benchmark_config_grouped_teacher_vs_oracle(gpu_device, precision):
-    """The launch mode bench.py times by default -- GroupedTeacherKDStep(group=2): the teacher over the 32 images of two
-    steps in one pass, cut into two graph segments, one beside each student step -- on BASELINE config 2 at full size,
+    """The launch mode bench.py times by default -- GroupedTeacherKDStep(group=3): the teacher over the 48 images of three
+    steps in one pass, cut into three graph segments, one beside each student step -- on BASELINE config 2 at full size,
     against the same oracle steps with the same bounds as the one-batch-per-pass pipeline above."""
-    _pipelined_graph_vs_oracle(gpu_device, precision, "darknet_tiny_h", False, full=False, group=2)
+    _pipelined_graph_vs_oracle(gpu_device, precision, "darknet_tiny_h", False, full=False, group=3)
 
 
 def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1):
