@@ -1,6 +1,10 @@
 """The dispatch sequence of ONE replayed KD step out of a rocprofv3 --kernel-trace result (rocpd sqlite .db).
 
-    python tools/step_sequence.py gpurun_out/<run>/prof/kd_results.db profiles/<name>.md
+    python tools/step_sequence.py gpurun_out/<run>/prof/kd_results.db profiles/<name>.md [period]
+
+period (default 1): with the grouped teacher pass (kd6d.graph.GroupedTeacherKDStep) the unit that repeats is `period` =
+group consecutive steps -- one teacher pass over their batches, cut into `period` segments, plus `period` student steps;
+the table then shows one whole period and the summary gives per-step figures (totals / period).
 
 A step is delimited by its closing `clip_adamw_kernel` dispatch: everything that started after the previous step's
 optimizer launch ended, up to and including this step's.  A bench invocation also holds eager warm-up, probe and
@@ -19,6 +23,7 @@ from rocprof_summary import short
 
 def main():
     db, out = sys.argv[1], sys.argv[2]
+    period = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("PRAGMA table_info(kernels)")]
     pick = lambda *names: next((n for n in names if n in cols), None)      # noqa: E731
@@ -31,13 +36,20 @@ def main():
     opt = [i for i, r in enumerate(rows) if "clip_adamw" in r[0]]
     if len(opt) < 3:
         raise SystemExit("need at least 3 optimizer launches in the trace, found %d" % len(opt))
-    spans = [(opt[i - 1] + 1, opt[i]) for i in range(1, len(opt))]
-    by_len = {}
-    for sp in spans:
-        by_len.setdefault(sp[1] - sp[0] + 1, []).append(sp)
-    n_mode, group = max(by_len.items(), key=lambda kv: len(kv[1]))
+    best = None
+    for off in range(period):              # where a period starts is not known: take the phase whose spans repeat most
+        spans = [(opt[i - period] + 1, opt[i]) for i in range(period + off, len(opt), period)]
+        by_len = {}
+        for sp in spans:
+            by_len.setdefault(sp[1] - sp[0] + 1, []).append(sp)
+        if not by_len:
+            continue
+        n_mode, group = max(by_len.items(), key=lambda kv: len(kv[1]))
+        if best is None or len(group) > len(best[1]):
+            best = (n_mode, group, spans)
+    n_mode, group, spans = best
     lo, hi = group[len(group) // 2]
-    back = "%d of %d steps with %d dispatches" % (len(group) // 2 + 1, len(group), n_mode)
+    back = "%d of %d %s with %d dispatches" % (len(group) // 2 + 1, len(group), "steps" if period == 1 else "periods of %d steps" % period, n_mode)
     step = rows[lo:hi + 1]
     t0 = step[0][1]
     ours = [r for r in step if not any(s in r[0] for s in ("at::", "rocclr", "ncclDevKernel"))]
@@ -45,7 +57,9 @@ def main():
         grid, wg = r[4], r[5]
         return (grid // wg) if (isinstance(grid, int) and isinstance(wg, int) and wg) else 0
     cu_time = sum((r[2] - r[1]) * min(1.0, (n_wg(r) or 256) / 256.0) for r in step) / 1e6
-    lines = ["# dispatches of one replayed KD step (rocprofv3 --kernel-trace)", "",
+    per = "" if period == 1 else " = %.1f dispatches, %.3f ms of kernel time, %.3f ms of CU-time PER STEP" % (
+        len(step) / period, sum(r[2] - r[1] for r in step) / 1e6 / period, cu_time / period)
+    lines = ["# dispatches of one replayed KD %s (rocprofv3 --kernel-trace)%s" % ("step" if period == 1 else "period of %d steps" % period, per), "",
              "source: `%s`, step %s (%d steps in the trace); columns of the `kernels` view used: %s" %
              (db, back, len(spans), ", ".join(x for x in (c_start, c_end, c_queue, c_grid, c_wg) if x)), "",
              "%d dispatches: %d kd6d kernels, %d torch / runtime (fills, copies, RNG); serialised span %.3f ms, "
