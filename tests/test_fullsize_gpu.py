@@ -282,6 +282,7 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
             d = abs(na - nb) / max(na, nb, 1e-30)
             if d > NOISY:
                 noisy[k] = d
+        twin0 = twins[0]
         del twins
         torch.cuda.empty_cache()
 
@@ -302,6 +303,16 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
     emulate = precision == "bf16"
     res1, ref_grads, res2 = _oracle_steps(arch, mixed, full, emulate, cpu_batches, choose, two_steps=not full)
     clip = min(1.0, 1.0 / (res1["grad_norm"] + 1e-6))
+    if noisy is not None and precision == "bf16" and group > 1:
+        # the grouped pass is a third execution of the same arithmetic (the teacher's layers tile 48 images instead of
+        # 16, so its cells agree with the twins' to rounding, not bitwise): a tensor on which it and a twin disagree by
+        # more than NOISY is not reproducible between launch modes either -- same treatment, same energy bound below
+        sub = _grads(student)
+        for k, a in twin0.items():
+            na, nb = float(a.norm()), float(sub[k].norm())
+            d = abs(na - nb) / max(na, nb, 1e-30)
+            if d > NOISY:
+                noisy[k] = max(d, noisy.get(k, 0.0))
     rep = _grad_report(student, ref_grads, clip, res1["grad_norm"], exclude=noisy)
     rep["not_reproducible"] = noisy
     # what is set aside this way must be a negligible part of the update: < 0.1 % of the squared gradient norm (measured:
