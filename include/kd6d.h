@@ -233,8 +233,10 @@ int kd6d_device_cu_count(void);
  *   bn.onepass      1 | 0 two-launch BatchNorm backward     bn.onepass_max  largest x in 16-B granules (65536)
  *   gn.onepass      1 | 0 two-launch GroupNorm backward     sinkhorn.lanes  1 | 0 general path for every point set
  *   conv.fuse_norm  bit 0: GroupNorm, bit 1: BatchNorm geometries may take kd6d_conv2d_fwd_norm (3 | 0: fusable() = 0)
- *   sinkhorn.dense_mfma  dense OT, D = 16: 1 gradient-free softmin passes on the fp32 matrix pipe while
- *                  eps >= 1.5e-4 diameter^2 | 0 never | 2 every gradient-free pass (error studies)
+ *   sinkhorn.dense_mfma  dense OT, D = 16: 1 softmin passes on the matrix pipe (inner products at fp32 accuracy from
+ *                  bf16 pieces; the gradient-carrying pass's weighted sums as a second product) while
+ *                  eps >= 1.5e-4 diameter^2 | 0 never | 2 every pass (error studies) | 3 as 1, the gradient-carrying
+ *                  softmins in the difference form
  * Unknown names return KD6D_ERR_ARG. */
 /* Context: the library's mutable state -- the option table, the pair bracket of kd6d_conv2d_pair_begin/_end and the
  * counter of in-kernel barrier waits that gave up -- lives in a kd6d_ctx.  Every entry point of this header acts on the

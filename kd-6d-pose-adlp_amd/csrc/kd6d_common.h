@@ -51,7 +51,8 @@ enum Kd6dOption {
   KD6D_OPT_SINKHORN_LANES,     // 1 | 0: every set on the general (one softmin after the other) path
   KD6D_OPT_CONV_HALO_PAIRING,  // 1 | 0: maps <= 32 wide keep the double-buffered (one workgroup per CU) halo tiles
   KD6D_OPT_CONV_FUSE_NORM,     // bit 0: GroupNorm, bit 1: BatchNorm geometries may take the fused launch (0: kd6d_conv2d_fwd_norm_fusable reports 0)
-  KD6D_OPT_SINKHORN_DENSE_MFMA,  // dense OT, D = 16: 1 the fp32 matrix-pipe softmin where its cancellation error allows | 0 never | 2 always
+  KD6D_OPT_SINKHORN_DENSE_MFMA,  // dense OT, D = 16: 1 the matrix-pipe softmins where their cancellation error allows | 0 never | 2 always
+                                 // | 3 as 1, but the gradient-carrying softmins of the last extrapolation keep the difference form
   KD6D_OPT_CONV_HALO_WIDE,     // 1 | 0: maps 65 ... 80 wide (480 x 640 full frames) stay off the halo-patch kernel
   KD6D_OPT_COUNT
 };

@@ -228,10 +228,35 @@ __device__ __forceinline__ void split3(float v, bf16_t& h, bf16_t& m, bf16_t& l)
   l = (bf16_t)(r1 - (float)m);
 }
 
-// centred points -> MFMA-ready pieces [point][piece h,m,l][k half][8 bf16] + |p - centre|^2, once per call
+typedef _Float16 f16_t;
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr int kYtBytes = 64;            // per point: 16 dimensions x (hi, lo) fp16
+constexpr float kLoScale = 2048.f;      // the lo pieces travel scaled by 2^11 (kept out of fp16's subnormal range)
+
+// centred points -> MFMA-ready pieces [point][piece h,m,l][k half][8 bf16] + |p - centre|^2, once per call.
+// `yt`: the same centred point as two fp16 pieces (hi, lo * 2^11) in the layout the gradient kernel's SECOND product
+// reads as its A operand -- per block of 32 points [k-step s][lane half h][row m = piece * 16 + dimension][8 points]:
+// the 8 points of (s, h) are the ones whose weights a lane of half h holds in accumulators 8 s .. 8 s + 7 of the first
+// product (point 16 s + 8 (e / 4) + 4 h + e % 4 at position e).  Points n .. the next multiple of 128 are written as zeros.
 __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ p, int n, const float* __restrict__ sums,
-                                                          float inv_count, char* __restrict__ out, float* __restrict__ n2) {
+                                                          float inv_count, char* __restrict__ out, float* __restrict__ n2,
+                                                          char* __restrict__ yt) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (yt != nullptr && i < ((n + 127) & ~127)) {
+    const int jj = i & 31, st = jj >> 4, rem = jj & 15, e = 4 * (rem >> 3) + (rem & 3), hf = (rem >> 2) & 1;
+    f16_t* base = reinterpret_cast<f16_t*>(yt + (size_t)(i >> 5) * (32 * kYtBytes)) + ((st * 2 + hf) * 32) * 8 + e;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      f16_t hi = (f16_t)0.f, lo = (f16_t)0.f;
+      if (i < n) {
+        const float v = p[(size_t)i * 16 + k] - sums[k] * inv_count;
+        hi = (f16_t)v;
+        lo = (f16_t)((v - (float)hi) * kLoScale);
+      }
+      base[k * 8] = hi;
+      base[(16 + k) * 8] = lo;
+    }
+  }
   if (i >= n) return;
   float center[16];
 #pragma unroll
@@ -258,6 +283,7 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restric
 struct DenseSplit {
   const char* xs; const char* ys;      // prepared points (kSplitBytes each)
   const float* xn2; const float* yn2;  // |p - centre|^2
+  const char* xt; const char* yt;      // the same points as the A operand of the gradient's second product (kYtBytes each)
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -429,10 +455,228 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   else a.pot_new[opot + row] = val;
 }
 
-// per-dimension SUM of a point set (D <= 16, 256 % D == 0) added into sums[D] (pre-zeroed): the centre the matrix-pipe
-// softmin subtracts is sums / (N + M) (dense_split_kernel).  (As one workgroup this took 0.34 ms of a 5.3-ms image.)
+// ---------------------------------------------------------------------------
+// The gradient-carrying softmins of the last extrapolation (rows of x: a_x over x, b_x over y) on the matrix pipe as well:
+// grad_i = sum_j w_ij (x_i - c_j) = x_i - (sum_j P_ij c_j) / (sum_j P_ij),  P_ij = exp2(v_ij - m_i)  (centred points: the
+// centre cancels).  The first product is the gradient-free kernel's; the second, O^T[piece * 16 + d][i] = sum_j C^T P^T, takes
+// the accumulators of the first AS its B operand: a lane holds, for row i = lane % 32, the 16 columns 8 q + 4 h + r of a
+// block, and accumulators 8 s .. 8 s + 7 are exactly the 8 k-values of lane half h in k-step s once the A operand lists the
+// columns in that order (dense_split_kernel's `yt`).  Both operands in two fp16 pieces, the lo ones scaled by 2^11: P = P_hi +
+// P_lo / 2^11 into two accumulators, C = C_hi + C_lo / 2^11 as rows 0-15 / 16-31 of A -- four v_mfma_f32_32x32x16_f16 per block
+// behind the six of the inner products, every term of order >= 2^-22 kept.  One pass: the running maximum is shared by the two
+// lanes of a row every tile (the second product sums over both lanes' columns, so they must scale alike), and O is rescaled with
+// the running sum when it moves.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float lane_pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+
+__global__ __launch_bounds__(256) void dense_softmin_mfma_grad_kernel(const DenseArgs a, const DenseSplit sp) {
+  __shared__ __attribute__((aligned(16))) char cs[2][kMTile * kMPitchB];
+  __shared__ __attribute__((aligned(16))) float hs[2][kMTile];
+  __shared__ __attribute__((aligned(16))) char yts[2][kMTile * kYtBytes];
+  const int which = a.which[blockIdx.y];          // 0: a_x (x <- x) or 3: b_x (x <- y): rows are points of x
+  const bool cols_x = which == 0;
+  const char* Rs = sp.xs;
+  const float* Rn2 = sp.xn2;
+  const char* Cs = cols_x ? sp.xs : sp.ys;
+  const char* Ct = cols_x ? sp.xt : sp.yt;
+  const float* Cn2 = cols_x ? sp.xn2 : sp.yn2;
+  const int nr = a.N;
+  const int nc = cols_x ? a.N : a.M;
+  const float* lw = cols_x ? a.la : a.lb;
+  const int cpot = which == 0 ? off_ax(a) : off_ay(a);
+  const int opot = which == 0 ? off_ax(a) : off_bx(a);
+  if (blockIdx.x * kMRows >= nr) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rgrp = wave & 1, chalf = wave >> 1, half = lane >> 5;
+  const int lrow = rgrp * 32 + (lane & 31);
+  const int row = blockIdx.x * kMRows + lrow;
+  const bool rok = row < nr;
+  const float inv_eps = 1.f / a.eps;
+  const float k2 = 0.5f * inv_eps * kLog2e;
+  bf16x8_t bh, bm_, bl;
+  {
+    const bf16x8_t* rp = reinterpret_cast<const bf16x8_t*>(Rs + (size_t)(rok ? row : 0) * kSplitBytes);
+    const bf16x8_t ph = rp[0 * 2 + half], pm = rp[1 * 2 + half], pl = rp[2 * 2 + half];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = rok ? ((float)ph[e] + (float)pm[e]) + (float)pl[e] : 0.f;
+      bf16_t h, m, l;
+      split3(2.f * k2 * v, h, m, l);
+      bh[e] = h; bm_[e] = m; bl[e] = l;
+    }
+  }
+  const float rr = rok ? Rn2[row] : 0.f;
+
+  int ldst[3], scol[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + 256 * j;
+    scol[j] = i / 6;
+    ldst[j] = scol[j] * kMPitchB + (i - scol[j] * 6) * 16;
+  }
+  u32x4_t sv[3], tv[2];
+  float s_lw = 0.f, s_pot = 0.f, s_n2 = 0.f;
+  const bool with_pot = a.mode != 0;
+  auto fetch = [&](int c0) {
+    const char* g = Cs + (size_t)c0 * kSplitBytes + (size_t)tid * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      sv[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c0 + scol[j] < nc) sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * 4096);
+    }
+    const char* gt = Ct + (size_t)c0 * kYtBytes + (size_t)tid * 16;      // padded to a multiple of 128 points, zeros
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tv[j] = *reinterpret_cast<const u32x4_t*>(gt + j * 4096);
+    if (tid < kMTile) {
+      const bool ok = c0 + tid < nc;
+      const int c = ok ? c0 + tid : 0;
+      s_lw = ok ? lw[c] : -INFINITY;
+      s_pot = with_pot ? a.pot_old[cpot + c] : 0.f;
+      s_n2 = Cn2[c];
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = sv[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4_t*>(&yts[buf][tid * 16 + j * 4096]) = tv[j];
+    if (tid < kMTile) hs[buf][tid] = (s_lw + s_pot * inv_eps) * kLog2e - k2 * s_n2;
+  };
+  auto block = [&](int buf, int blk) {
+    f32x16_t acc;
+    const float* hb = &hs[buf][blk * 32];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(hb + 4 * half + 8 * u);
+      acc[4 * u + 0] = h4[0]; acc[4 * u + 1] = h4[1]; acc[4 * u + 2] = h4[2]; acc[4 * u + 3] = h4[3];
+    }
+    const char* col = &cs[buf][(blk * 32 + (lane & 31)) * kMPitchB + half * 16];
+    const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(col);
+    const bf16x8_t am = *reinterpret_cast<const bf16x8_t*>(col + 32);
+    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(col + 64);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm_, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm_, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
+  };
+
+  f32x16_t o1, o2;                     // sum_j P_hi C^T  and  2^11 sum_j P_lo C^T  (rows: 8 q + 4 half + r of [C_hi; 2^11 C_lo])
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { o1[u] = 0.f; o2[u] = 0.f; }
+  // P of one block (in place of its accumulators) -> two fp16 operands per k-step -> four products
+  auto second = [&](int buf, int blk, const f32x16_t& pv) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      f16x8_t phi, plo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pf = pv[8 * st + e];
+        const f16_t h = (f16_t)pf;
+        phi[e] = h;
+        plo[e] = (f16_t)((pf - (float)h) * kLoScale);
+      }
+      const f16x8_t ay = *reinterpret_cast<const f16x8_t*>(&yts[buf][blk * (32 * kYtBytes) + ((st * 2 + half) * 32 + (lane & 31)) * 16]);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay, phi, o1, 0, 0, 0);
+      o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay, plo, o2, 0, 0, 0);
+    }
+  };
+
+  float m = -1e30f, s = 0.f;
+  const int ntiles = (nc + kMTile - 1) / kMTile;
+  fetch(0);
+  put(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    fetch((t + 1 < ntiles ? t + 1 : t) * kMTile);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16_t acc0 = block(buf, 2 * chalf);
+    f32x16_t acc1 = block(buf, 2 * chalf + 1);
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mn = fmaxf(fmaxf(mn, acc0[2 * u]), acc0[2 * u + 1]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mn = fmaxf(fmaxf(mn, acc1[2 * u]), acc1[2 * u + 1]);
+    mn = lane_pair_max(mn);
+    const float sc = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    const f32x2_t mn2 = {mn, mn};
+    f32x2_t add = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f32x2_t d0 = f32x2_t{acc0[2 * u], acc0[2 * u + 1]} - mn2;
+      const f32x2_t d1 = f32x2_t{acc1[2 * u], acc1[2 * u + 1]} - mn2;
+      acc0[2 * u] = __builtin_amdgcn_exp2f(d0[0]); acc0[2 * u + 1] = __builtin_amdgcn_exp2f(d0[1]);
+      acc1[2 * u] = __builtin_amdgcn_exp2f(d1[0]); acc1[2 * u + 1] = __builtin_amdgcn_exp2f(d1[1]);
+      add += f32x2_t{acc0[2 * u], acc0[2 * u + 1]};
+      add += f32x2_t{acc1[2 * u], acc1[2 * u + 1]};
+    }
+    s = s * sc + (add[0] + add[1]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { o1[u] *= sc; o2[u] *= sc; }
+    second(buf, 2 * chalf, acc0);
+    second(buf, 2 * chalf + 1, acc1);
+    __asm__ volatile("" : "+v"(m), "+v"(s));
+    __builtin_amdgcn_sched_barrier(0);
+    put(buf ^ 1);
+    __syncthreads();
+  }
+  // the two lanes of a row scaled alike all along: their sums add.  Then the two column halves (waves w and w + 2): through
+  // LDS (the tile buffers are free now), with a rescale to the common maximum.
+  s += __shfl_xor(s, 32, 64);
+  float* mrg = reinterpret_cast<float*>(&cs[0][0]);                  // [rgrp][lane][34]
+  float* mine = mrg + ((size_t)rgrp * 64 + lane) * 34;
+  if (chalf == 1) {
+    mine[0] = m; mine[1] = s;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { mine[2 + u] = o1[u]; mine[18 + u] = o2[u]; }
+  }
+  __syncthreads();
+  if (chalf != 0 || !rok) return;
+  {
+    const float m2 = mine[0], s2 = mine[1];
+    const float mn = fmaxf(m, m2);
+    const float c1 = __builtin_amdgcn_exp2f(m - mn), c2 = __builtin_amdgcn_exp2f(m2 - mn);
+    s = s * c1 + s2 * c2;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { o1[u] = o1[u] * c1 + mine[2 + u] * c2; o2[u] = o2[u] * c1 + mine[18 + u] * c2; }
+    m = mn;
+  }
+  if (half == 0) {
+    const float lse = (m + __builtin_amdgcn_logf(s) - k2 * rr) * kLn2;
+    a.pot_new[opot + row] = -a.lam * a.eps * lse;                    // (mode 2: the last extrapolation is not averaged)
+  }
+  // this lane's 8 dimensions: d = 8 q + 4 half + r for q = 0, 1 (accumulator 4 q + r = the hi rows, 8 + 4 q + r = the lo rows)
+  const float inv_s = 1.f / s;
+  const float il = 1.f / kLoScale;
+  float* go = (which == 0 ? a.grad_xx : a.grad_xy) + (size_t)row * 16;
+  const bf16x8_t* rp = reinterpret_cast<const bf16x8_t*>(Rs + (size_t)row * kSplitBytes);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const bf16x8_t ph = rp[0 * 2 + q], pm = rp[1 * 2 + q], pl = rp[2 * 2 + q];      // dimensions 8 q .. 8 q + 7 of x_i - centre
+    f32x4_t g4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = 4 * half + r;
+      const float xi = ((float)ph[e] + (float)pm[e]) + (float)pl[e];
+      const float bary = (o1[4 * q + r] + o1[8 + 4 * q + r] * il) + (o2[4 * q + r] + o2[8 + 4 * q + r] * il) * il;
+      g4[r] = xi - bary * inv_s;
+    }
+    *reinterpret_cast<f32x4_t*>(go + 8 * q + 4 * half) = g4;
+  }
+}
+
+// per-dimension SUM of both point sets (D <= 16, 256 % D == 0): the centre the matrix-pipe softmin subtracts is
+// sums / (N + M) (dense_split_kernel).  Two stages, both with a FIXED summation order -- kCenterWgs partial sums per set,
+// then one small workgroup adds them up: the centre cancels mathematically, but its last bits decide how every point
+// splits into pieces, and at blur 0.001 the gradient turns a 1e-7 difference there into 2e-3 (float atomics made two
+// runs on the same inputs differ by that much).  (As ONE workgroup the whole reduction took 0.34 ms of a 5.3-ms image.)
+constexpr int kCenterWgs = 64;
 __global__ __launch_bounds__(256) void dense_center_kernel(const float* __restrict__ p, long long n_floats, int D,
-                                                           float* __restrict__ sums) {
+                                                           float* __restrict__ partials) {
   __shared__ float part[256];
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_floats; i += (long long)gridDim.x * 256) acc += p[i];
@@ -441,8 +685,15 @@ __global__ __launch_bounds__(256) void dense_center_kernel(const float* __restri
   if ((int)threadIdx.x < D) {
     float t = 0.f;
     for (int j = threadIdx.x; j < 256; j += D) t += part[j];
-    atomicAdd(sums + threadIdx.x, t);
+    partials[blockIdx.x * 16 + threadIdx.x] = t;
   }
+}
+
+__global__ void dense_center_finalize_kernel(const float* __restrict__ partials, int n_partials, int D, float* __restrict__ sums) {
+  if ((int)threadIdx.x >= D) return;
+  float t = 0.f;
+  for (int j = 0; j < n_partials; ++j) t += partials[j * 16 + threadIdx.x];
+  sums[threadIdx.x] = t;
 }
 
 // log weights (with geomloss' -1e5 for non-positive weights)
@@ -538,15 +789,20 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   const bool use_mfma = D == 16 && kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) != 0;
   DenseSplit sp;
   sp.xs = splits; sp.ys = splits + (size_t)N * kSplitBytes; sp.xn2 = n2; sp.yn2 = n2 + N;
+  const size_t n128 = ((size_t)N + 127) & ~(size_t)127, m128 = ((size_t)M + 127) & ~(size_t)127;
+  char* yt0 = splits + ((size_t)N + M) * kSplitBytes;          // 16-byte aligned: kSplitBytes is a multiple of 16
+  sp.xt = yt0; sp.yt = yt0 + n128 * kYtBytes;
   if (use_mfma) {
-    if (hipMemsetAsync(center, 0, 16 * sizeof(float), st) != hipSuccess) return KD6D_ERR_LAUNCH;
-    hipLaunchKernelGGL(dense_center_kernel, dim3(64), dim3(256), 0, st, x, (long long)N * D, D, center);
-    hipLaunchKernelGGL(dense_center_kernel, dim3(64), dim3(256), 0, st, y, (long long)M * D, D, center);
+    // (the partial sums borrow the head of the A-operand array: dense_split_kernel fills it afterwards; >= 4096 floats)
+    float* partials = reinterpret_cast<float*>(yt0);
+    hipLaunchKernelGGL(dense_center_kernel, dim3(kCenterWgs), dim3(256), 0, st, x, (long long)N * D, D, partials);
+    hipLaunchKernelGGL(dense_center_kernel, dim3(kCenterWgs), dim3(256), 0, st, y, (long long)M * D, D, partials + kCenterWgs * 16);
+    hipLaunchKernelGGL(dense_center_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)partials, 2 * kCenterWgs, D, center);
     const float inv_count = 1.0f / (float)((long long)N + M);
-    hipLaunchKernelGGL(dense_split_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, N, (const float*)center, inv_count,
-                       splits, n2);
-    hipLaunchKernelGGL(dense_split_kernel, dim3((M + 255) / 256), dim3(256), 0, st, y, M, (const float*)center, inv_count,
-                       splits + (size_t)N * kSplitBytes, n2 + N);
+    hipLaunchKernelGGL(dense_split_kernel, dim3((unsigned)(n128 / 256 + 1)), dim3(256), 0, st, x, N, (const float*)center, inv_count,
+                       splits, n2, yt0);
+    hipLaunchKernelGGL(dense_split_kernel, dim3((unsigned)(m128 / 256 + 1)), dim3(256), 0, st, y, M, (const float*)center, inv_count,
+                       splits + (size_t)N * kSplitBytes, n2 + N, yt0 + n128 * kYtBytes);
   }
   hipLaunchKernelGGL(dense_logw_kernel, dim3((N + 255) / 256), dim3(256), 0, st, alpha, la, N);
   hipLaunchKernelGGL(dense_logw_kernel, dim3((M + 255) / 256), dim3(256), 0, st, beta, lb, M);
@@ -591,7 +847,12 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
       // the last extrapolation: only the two softmins over the rows of x (a_x, b_x) carry a gradient -- difference form,
       // with the softmax-weighted sums; the other two (b_y, a_y) are plain potentials
       set_which(0, 3, 0, 0);
-      hipLaunchKernelGGL((dense_softmin_kernel<D, true, 4>), dim3((nmax + 127) / 128, 2), dim3(kThreadsD), 0, st, a);
+      if (mfma_ok && kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) != 3) {
+        if constexpr (D == 16)
+          hipLaunchKernelGGL(dense_softmin_mfma_grad_kernel, dim3((N + kMRows - 1) / kMRows, 2), dim3(256), 0, st, a, sp);
+      } else {
+        hipLaunchKernelGGL((dense_softmin_kernel<D, true, 4>), dim3((nmax + 127) / 128, 2), dim3(kThreadsD), 0, st, a);
+      }
       set_which(1, 2, 0, 0);
       if (mfma_ok) {
         if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
@@ -622,7 +883,9 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
 extern "C" int64_t kd6d_sinkhorn_dense_workspace_floats(int N, int M, int D) {
   // log weights, two potential sets, two gradient partials, centre (+ pad), and for D = 16 the matrix-pipe softmin's
   // prepared points: |p|^2 and 96 bytes of bf16 pieces per point
-  return (int64_t)N + M + 4 * ((int64_t)N + M) + 2 * (int64_t)N * D + 64 + (D == 16 ? 25 * ((int64_t)N + M) + 16 : 0);
+  // ... and 64 bytes of fp16 pieces per point (sets padded to multiples of 128 points) for the gradient's second product
+  return (int64_t)N + M + 4 * ((int64_t)N + M) + 2 * (int64_t)N * D + 64 +
+         (D == 16 ? 25 * ((int64_t)N + M) + 16 + 16 * ((((int64_t)N + 127) & ~127ll) + (((int64_t)M + 127) & ~127ll)) : 0);
 }
 
 extern "C" int kd6d_sinkhorn_dense_diameter(const float* x, const float* y, int N, int M, int D, float* scratch64,

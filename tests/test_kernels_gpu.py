@@ -1289,7 +1289,7 @@ def test_conv_block_bn_on_load(gpu_device, dtype, case):
 
 
 @pytest.mark.parametrize("blur", [0.05, 0.001])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 def test_sinkhorn_dense_matrix_pipe_softmin(gpu_device, blur, mode):
     """D = 16 (BASELINE config 5's code dimension): the gradient-free softmin passes on the fp32 matrix pipe
     (dense_softmin_mfma_kernel: r.c from v_mfma_f32_32x32x2_f32, |r|^2 + |c|^2 - 2 r.c form on centred points, taken
@@ -1313,6 +1313,33 @@ def test_sinkhorn_dense_matrix_pipe_softmin(gpu_device, blur, mode):
     np.testing.assert_allclose(loss.cpu().numpy(), S_r, rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(gx.cpu().numpy(), gx_r[0], rtol=5e-3, atol=5e-3 * np.abs(gx_r).max())
     np.testing.assert_allclose(ga.cpu().numpy(), ga_r[0], rtol=5e-3, atol=5e-3 * np.abs(ga_r).max())
+
+
+@pytest.mark.parametrize("N,M", [(900, 777), (64, 130), (1000, 333), (129, 64)])
+def test_sinkhorn_dense_gradient_as_second_product(gpu_device, N, M):
+    """The two gradient-carrying softmins of the last extrapolation on the matrix pipe (dense_softmin_mfma_grad_kernel: the
+    softmax-weighted sums as a second product whose B operand is the first product's accumulators, fp16 pieces hi +
+    lo / 2^11 on both sides) against the difference form on the SAME inputs (option 3 = the same passes, gradient form on
+    the VALU): values to 1e-6, gradients to 2e-4 of scale -- and not bitwise equal, i.e. the kernel under test did run.
+    Ragged row counts (not multiples of 64) and column counts (not multiples of 128: the padded A-operand tiles)."""
+    ops = _ops()
+    D, reach, blur = 16, 0.5, 0.05
+    x, a, y, b = _dense_problem(N, M, D, 23, reach)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    res = {}
+    for mode in (1, 3):
+        _option("sinkhorn.dense_mfma", mode)
+        loss, gx, ga = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach)
+        torch.cuda.synchronize()
+        res[mode] = (float(loss), gx.cpu().numpy(), ga.cpu().numpy())
+    assert np.isfinite(res[1][1]).all() and np.isfinite(res[1][2]).all()
+    assert res[1][0] == pytest.approx(res[3][0], rel=2e-6)
+    sg, sa = np.abs(res[3][1]).max(), np.abs(res[3][2]).max()
+    egx = float(np.abs(res[1][1] - res[3][1]).max() / sg)
+    ega = float(np.abs(res[1][2] - res[3][2]).max() / sa)
+    print("[dense OT second product %dx%d] grad_x %.2e, grad_alpha %.2e of scale" % (N, M, egx, ega))
+    assert egx <= 2e-4 and ega <= 2e-5, (egx, ega)
+    assert not np.array_equal(res[1][1], res[3][1]), "option 1 did not take the matrix-pipe gradient kernel"
 
 
 def test_context_isolates_options_pair_bracket_and_timeouts(gpu_device):
