@@ -587,10 +587,14 @@ def bench_dense(args, out_fd):
         eps_list = [diam * diam] + [float(np.exp(2 * np.log(diam) + i * 2 * np.log(kd["SCALING"]))) for i in range(n_eps - 2)] + [blur * blur]
         on_mfma = D == 16 and ops.get_option("sinkhorn.dense_mfma") != 0
         thr = 0.0 if ops.get_option("sinkhorn.dense_mfma") == 2 else 1.5e-4 * diam * diam
-        # (of the last extrapolation's four softmins the two without a gradient go there too)
-        n_mfma = (4 * (1 + sum(1 for e in eps_list if e >= thr)) + (2 if eps_list[-1] >= thr else 0)) if on_mfma else 0
+        # (the last extrapolation's four softmins go there too: the two without a gradient as they are, the two with one
+        #  with the weighted sums as a second product -- four more MFMAs of the same shape per 32 x 32 pairs, 128 FLOP per
+        #  pair; option 3 keeps those two in the difference form)
+        last_on = eps_list[-1] >= thr
+        grad_on = last_on and ops.get_option("sinkhorn.dense_mfma") != 3
+        n_mfma = (4 * (1 + sum(1 for e in eps_list if e >= thr)) + (2 if last_on else 0) + (2 if grad_on else 0)) if on_mfma else 0
         n_diff = passes - n_mfma
-        mfma_flop = n_mfma * float(N) * float(M) * 6 * 2 * D
+        mfma_flop = (n_mfma * 6 * 2 * D + (2 * 4 * 2 * D if (on_mfma and grad_on) else 0)) * float(N) * float(M)
         laneops = n_diff * float(N) * float(M) * (2 * D + 8)
         peak = PEAK_F32 / 2                         # lane-ops/s of the fp32 vector pipes (157.3 TFLOP/s counts FMA twice)
         results.append({"blur": blur, "diameter": diam, "eps_steps": n_eps, "softmin_passes": passes,
@@ -612,11 +616,12 @@ def bench_dense(args, out_fd):
         "config": {"workload": "BASELINE config 5 (configs/dense16d.yaml): N = M = %d cells, D = %d, p=2, blur %s, scaling %s, "
                                "reach %s; the reference cannot run this size (geomloss needs KeOps above 5000^2 pairs)"
                                % (N, D, head["blur"], kd["SCALING"], kd["REACH"]), "parallelism": "replicas x%d" % world},
-        "roofline": ({"bound": "mfma", "kernel": "dense_softmin_mfma_kernel (inner products of the gradient-free softmin passes: "
-                                                  "six v_mfma_f32_32x32x16_bf16 on three-way bf16-split fp32 operands per 32x32 pairs)",
+        "roofline": ({"bound": "mfma", "kernel": "dense_softmin_mfma_kernel / dense_softmin_mfma_grad_kernel (inner products of the softmin passes: "
+                                                  "six v_mfma_f32_32x32x16_bf16 on three-way bf16-split fp32 operands per 32x32 pairs; the "
+                                                  "gradient-carrying pass adds four v_mfma_f32_32x32x16_f16 for the weighted sums)",
                       "achieved": head["mfma_tflops_over_whole_time"], "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                       "frac": head["mfma_tflops_over_whole_time"] * 1e12 / PEAK_BF16, "traffic": None,
-                      "basis": "192 FLOP per pair x pairs of the %d matrix-pipe passes / WALL time of the whole image (the %d "
+                      "basis": "192 FLOP per pair x pairs of the %d matrix-pipe passes (+ 128 per pair of the two gradient-carrying ones) / WALL time of the whole image (the %d "
                                "difference-form passes -- %.0f %% of the fp32 vector peak over the same time -- included)"
                                % (head["passes_matrix_pipe"], head["passes_difference_form"], 100 * head["frac_of_fp32_vector_peak"])}
                      if head["passes_matrix_pipe"] else
