@@ -172,6 +172,31 @@ def _encoded_pose_logits(targets, levels, B, noise, rng):
     return cls, reg
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_train_entry_pipelined_takes_exactly_max_iter_steps(gpu_device, tmp_path, group):
+    """train_kd.py --launch pipeline [--teacher_group 2] on synthetic batches: the pipeline holds 1 (2 * group) batches that
+    have not had their student step when the loop approaches MAX_ITER; the loop stops feeding and drains them with flush(),
+    so the checkpoint written at step MAX_ITER says exactly MAX_ITER optimiser steps -- 7 is neither a multiple of the
+    group nor of the period -- and training ends normally."""
+    import subprocess
+    wd = str(tmp_path) + "/"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_kd.py"), "--config_file", "configs/ape.yaml", "--config_file_t",
+           "configs/ape.yaml", "--backbone", "darknet_tiny_h", "--backbone_t", "darknet53", "--kd_weight", "5.",
+           "--working_dir", wd, "--synthetic", "--skip_teacher_eval", "--launch", "pipeline", "--teacher_group", str(group),
+           "--max_iters", "7", "--val_freq", "7", "--batch_size", "2", "--image_size", "64"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "Training finished" in r.stdout
+    outs = [os.path.join(d, f) for d, _, fs in os.walk(wd) for f in fs]
+    latest = [f for f in outs if f.endswith("latest.pth")]
+    assert latest, outs
+    ck = torch.load(latest[0], map_location="cpu", weights_only=False)
+    assert ck["steps"] == 7
+    assert ck["optim"]["steps"] == 7
+    assert ck["sched"]["last_epoch"] == 7
+
+
 def test_teacher_pnp_gate(gpu_device):
     """postprocess_kd.py:187-202: an image's teacher cells are kept only if RANSAC-PnP recovers a pose from them.
     Image 0's cells vote a consistent pose (0.5 px noise) and stay; image 1's votes are scrambled (60 px) and go."""
