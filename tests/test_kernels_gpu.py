@@ -400,7 +400,9 @@ def test_pack_dgrad_weights(gpu_device):
     ops = _ops()
     dev = gpu_device
     g = torch.Generator().manual_seed(3)
-    shapes = [(16, 8, 3), (8, 16, 1), (40, 24, 3)]
+    # (cout, cin, k): narrow layers (element-wise path) and cin % 64 == 0, cout % 16 == 0 layers (the LDS-tiled path: 16 x 64
+    # tiles, more tiles than blocks for 240 x 128 x 3 x 3 and fewer for 16 x 64 x 1 x 1)
+    shapes = [(16, 8, 3), (8, 16, 1), (40, 24, 3), (128, 128, 3), (240, 128, 3), (16, 64, 1), (64, 256, 1), (48, 192, 3)]
     for dtype in DTYPES:
         ws = [torch.randn(o, k, k, i, generator=g).to(dtype) for (o, i, k) in shapes]
         flat = torch.cat([w.reshape(-1) for w in ws]).to(dev)
