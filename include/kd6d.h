@@ -237,6 +237,7 @@ int kd6d_device_cu_count(void);
  *                  bf16 pieces; the gradient-carrying pass's weighted sums as a second product) while
  *                  eps >= 1.5e-4 diameter^2 | 0 never | 2 every pass (error studies) | 3 as 1, the gradient-carrying
  *                  softmins in the difference form
+ *   conv.smallc_wmax  widest map the resident-patch kernel (3x3, 8-32 input channels) takes: 640 | 256 (rounds 1-2)
  * Unknown names return KD6D_ERR_ARG. */
 /* Context: the library's mutable state -- the option table, the pair bracket of kd6d_conv2d_pair_begin/_end and the
  * counter of in-kernel barrier waits that gave up -- lives in a kd6d_ctx.  Every entry point of this header acts on the

@@ -1336,7 +1336,12 @@ bool dispatch_smallc(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t s
     if (q.in_w > wmax) wmax = q.in_w;
     rows += g->batch * q.in_h * q.in_w;
   }
-  if (wmax > 256) return false;
+  // the patch is 256 pixels + a halo of (width + 1) rows on either side: up to 256-wide maps always (the size the kernel
+  // was tuned on), wider ones (the 640- and 320-wide levels of full frames) while it stays within 32 KB, i.e. 8 or 16
+  // channels -- read amplification (256 + 2 halo) / 256 grows to 6x at 640, all of it L2 hits, against 9 taps on the
+  // generic kernels: 480 x 640 x 8 -> 32 forward 298 -> 165 us, 8 -> 8 forward / dgrad 266 / 289 -> 78 / 79,
+  // 240 x 320 x 8 -> 16 71 / 90 -> 24 / 33; with 32 channels (57 KB, one or two workgroups per CU) 129 -> 216, excluded
+  if (wmax > 256 && (wmax > (int)kd6d_opt(KD6D_OPT_CONV_SMALLC_WMAX) || (256 + 2 * (wmax + 1) + 1) * 2 * p.C > 32768)) return false;
   const int halo = wmax + 1;
   const int nb = p.N <= 16 ? 1 : (p.N <= 32 ? 2 : (p.N <= 64 ? 4 : 8));
 #define KD6D_SMALLC_CASE(CG_, NB_) \

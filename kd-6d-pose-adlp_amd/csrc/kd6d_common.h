@@ -54,6 +54,7 @@ enum Kd6dOption {
   KD6D_OPT_SINKHORN_DENSE_MFMA,  // dense OT, D = 16: 1 the matrix-pipe softmins where their cancellation error allows | 0 never | 2 always
                                  // | 3 as 1, but the gradient-carrying softmins of the last extrapolation keep the difference form
   KD6D_OPT_CONV_HALO_WIDE,     // 1 | 0: maps 65 ... 80 wide (480 x 640 full frames) stay off the halo-patch kernel
+  KD6D_OPT_CONV_SMALLC_WMAX,   // widest map the resident-patch kernel takes (640; 256 = the limit of rounds 1-2)
   KD6D_OPT_COUNT
 };
 long long kd6d_opt(int id);          // of the calling thread's current context

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 from kd6d import ops  # noqa: E402
 
-from step_layers import B, STUDENT, TEACHER  # noqa: E402
+from step_layers import B, STUDENT, STUDENT_640, TEACHER, TEACHER_640  # noqa: E402
 
 
 EAGER = False
@@ -76,6 +76,8 @@ def main():
     EAGER = a.eager
     dev = torch.device("cuda:0")
     shapes = (TEACHER if a.set in ("teacher", "all") else []) + (STUDENT if a.set in ("student", "all") else [])
+    if a.set in ("teacher640", "student640"):          # the full-frame variant (480 x 640) of the same step
+        shapes = TEACHER_640 if a.set == "teacher640" else STUDENT_640
     kinds = ["fwd", "dgrad", "wgrad"] if a.kind == "all" else [a.kind]
     print("| layer | kind | M | Cout | K | GFLOP | us | TFLOP/s |")
     print("|---|---|---|---|---|---|---|---|")
@@ -93,7 +95,7 @@ def main():
         dw = torch.zeros(cout * k * k * cin, dtype=torch.float32, device=dev)
         flop = 2.0 * geom.rows_out * cout * k * k * cin
         for kind in kinds:
-            if name.startswith("t.") and kind != "fwd":
+            if name.startswith(("t.", "t640.")) and kind != "fwd":
                 continue
             if kind == "fwd" and a.stats >= 0:
                 yf = torch.empty(geom.rows_out, cout, dtype=torch.float32, device=dev)
