@@ -454,7 +454,8 @@ def main():
         import glob
         tfiles = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_conv_hbm_traffic.json")))
         tpath = tfiles[-1] if tfiles else ""          # the latest round's PMC passes (tools/pmc_traffic.sh on the closing state)
-        if tpath and args.student == "darknet_tiny_h" and not full and B == 16 and args.precision == "bf16" and not args.opt:
+        if (tpath and args.student == "darknet_tiny_h" and not full and B == 16 and args.precision == "bf16" and not args.opt
+                and group == 3):      # (the file describes the default schedule: grouped teacher pass, group 3)
             # HBM bytes of the conv family per step from rocprofv3 PMC passes (tools/pmc_traffic.sh, FETCH_SIZE x2
             # per the gfx950 correction + WRITE_SIZE), committed with the profile it was taken from
             with open(tpath) as f:
