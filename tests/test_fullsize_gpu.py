@@ -303,10 +303,12 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
     emulate = precision == "bf16"
     res1, ref_grads, res2 = _oracle_steps(arch, mixed, full, emulate, cpu_batches, choose, two_steps=not full)
     clip = min(1.0, 1.0 / (res1["grad_norm"] + 1e-6))
-    if noisy is not None and precision == "bf16" and group > 1:
-        # the grouped pass is a third execution of the same arithmetic (the teacher's layers tile 48 images instead of
-        # 16, so its cells agree with the twins' to rounding, not bitwise): a tensor on which it and a twin disagree by
-        # more than NOISY is not reproducible between launch modes either -- same treatment, same energy bound below
+    if noisy is not None and precision == "bf16":
+        # the step under test is a third execution of the same arithmetic (in the grouped mode the teacher's layers even
+        # tile 48 images instead of 16, so its cells agree with the twins' to rounding, not bitwise): a tensor on which it
+        # and a twin disagree by more than NOISY is not reproducible either -- two twins that happen to agree with each
+        # other do not make it so (seen once in ~10 runs of the full-frame case: one 64-element BatchNorm gain at 0.21
+        # against the bound of 0.2, not flagged by the twins of that run) -- same treatment, same energy bound below
         sub = _grads(student)
         for k, a in twin0.items():
             na, nb = float(a.norm()), float(sub[k].norm())
