@@ -166,8 +166,11 @@ TOL = {
     # r03_fullsize_parity.json): loss_cls 3e-5 / 1.2e-4 / 3e-6, loss_reg 1.2e-4 / 3.3e-4 / 2.3e-3, loss_kd 3.3e-3 / 8.5e-3 ... 2.4e-2 /
     # 1.1e-3, global gradient norm 1.8e-4 / 1.4e-4 / 2.0e-4, per-tensor norm worst (reproducible tensors) 0.046 / 0.048 /
     # 0.10, tensors >= 1024 elements 0.018 / 0.024 / 0.050, weighted mean 2.0e-4 / 1.6e-4 / 2.1e-4, 1 - cosine 9e-5 / 4e-5 /
-    # 1e-5, second-step losses <= 1e-3 (kd 2.1e-2), update-sign agreement 0.974 / 0.968 / 0.978
-    "bf16": dict(loss=4e-3, kd=4e-2, gn=1e-3, worst=0.2, worst1k=0.1, wmean=6e-4, cos=3e-4, loss2=3e-3, sign=0.955),
+    # 1e-5, update-sign agreement 0.974 / 0.968 / 0.978.  Second-step losses (after ONE clipped AdamW update of lr 1e-3, i.e.
+    # +-lr per element with 2.5-3 % of the signs in disagreement): cls <= 2e-4, reg 2e-4 ... 1.5e-3 on config 2 and 1.4e-3 /
+    # 1.9e-3 / 2.3e-3 / 2.8e-3 on config 4 in four runs of the same tree -- run-to-run noise of the HIP path, not drift: the
+    # bound for it is 6e-3
+    "bf16": dict(loss=4e-3, kd=4e-2, gn=1e-3, worst=0.2, worst1k=0.1, wmean=6e-4, cos=3e-4, loss2=6e-3, sign=0.955),
 }
 # two runs of the HIP path on the same inputs: a per-tensor gradient norm that moves by more than this is noise
 NOISY = 0.03
