@@ -172,8 +172,9 @@ TOL = {
     # bound for it is 6e-3
     "bf16": dict(loss=4e-3, kd=4e-2, gn=1e-3, worst=0.2, worst1k=0.1, wmean=6e-4, cos=3e-4, loss2=6e-3, sign=0.955),
 }
-# two runs of the HIP path on the same inputs: a per-tensor gradient norm that moves by more than this is noise
-NOISY = 0.03
+# three runs of the HIP path on the same inputs (two twins + the step under test): a per-tensor gradient norm that moves
+# by more than this between any two of them is noise
+NOISY = 0.02
 # a bf16 step against the fp32 oracle (format error included): the round-2 bounds, for the record
 TOL_BF16_VS_FP32 = dict(loss=3e-3, kd=4e-2, gn=1e-3, worst=1.3, worst1k=0.3, wmean=2e-3, cos=1e-3)
 
@@ -285,7 +286,7 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
             d = abs(na - nb) / max(na, nb, 1e-30)
             if d > NOISY:
                 noisy[k] = d
-        twin0 = twins[0]
+        twin0, twin1 = twins
         del twins
         torch.cuda.empty_cache()
 
@@ -313,16 +314,21 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
         # other do not make it so (seen once in ~10 runs of the full-frame case: one 64-element BatchNorm gain at 0.21
         # against the bound of 0.2, not flagged by the twins of that run) -- same treatment, same energy bound below
         sub = _grads(student)
+        pairdev = {}
         for k, a in twin0.items():
-            na, nb = float(a.norm()), float(sub[k].norm())
-            d = abs(na - nb) / max(na, nb, 1e-30)
-            if d > NOISY:
-                noisy[k] = max(d, noisy.get(k, 0.0))
+            n3 = [float(a.norm()), float(twin1[k].norm()), float(sub[k].norm())]
+            pairdev[k] = (max(n3) - min(n3)) / max(max(n3), 1e-30)        # the largest of the three pairwise deviations
+            if pairdev[k] > NOISY:
+                noisy[k] = pairdev[k]
     rep = _grad_report(student, ref_grads, clip, res1["grad_norm"], exclude=noisy)
     rep["not_reproducible"] = noisy
+    if precision == "bf16":          # how reproducible the tensor that sets `worst_norm` was among the three executions
+        rep["worst_norm_run_to_run"] = pairdev.get(rep["worst_norm_name"])
     # what is set aside this way must be a negligible part of the update: < 0.1 % of the squared gradient norm (measured:
-    # 10-20 of 150 tensors, nearly all BatchNorm gains / biases and narrow convolutions of the student's backbone, two-run
-    # deviation 3-21 %; FPN and head, where 99.9 % of the gradient's norm is, reproduce)
+    # 20-27 of 150 tensors at NOISY = 2 % over three executions, nearly all BatchNorm gains / biases and narrow convolutions
+    # of the student's backbone, run-to-run deviation 2-21 %; FPN and head, where 99.9 % of the gradient's norm is,
+    # reproduce.  The tensors that remain deviate from the emulation by 0.02-0.08 at most -- `worst_norm_run_to_run` records
+    # how reproducible the one that sets the maximum was)
     assert sum(float(ref_grads[k].norm()) ** 2 for k in noisy) <= 1e-3 * res1["grad_norm"] ** 2, noisy
     if emulate and not full:
         # for the record: the same bf16 step against the plain fp32 oracle (number-format error included)
