@@ -168,6 +168,9 @@ if __name__ == "__main__":
         from kd6d.graph import GraphedKDStep, GroupedTeacherKDStep
         group = int(cfg["RUNTIME"].get("TEACHER_GROUP", 1))
         if launch == "pipeline" and group > 1:
+            if cfg["RUNTIME"]["DISTRIBUTED"] and get_rank() == 0:
+                print("note: --teacher_group %d beside a gradient exchange measured SLOWER than --teacher_group 1 in the "
+                      "one-rank rehearsal (DESIGN.md section 7); bench.py takes group 1 whenever a process group is alive" % group)
             # the teacher over the batches of `group` steps in one pass (2 * group batches in flight)
             gstep = GroupedTeacherKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd, group=group)
         else:
