@@ -15,6 +15,9 @@ images of three consecutive steps in one pass, cut into three hipGraph segments 
 teacher's stream beside each student step; every batch still gets exactly one teacher forward and one student step.  The timed
 region is aligned so that it ENDS with a completed pass: it holds ceil(K / group) passes, i.e. >= K * B images through
 the teacher (`config.teacher_images_in_timed_region`).  --teacher-group 1 = one teacher forward per step (rounds 1-2).
+Under a process group (N > 1, or the one-rank rehearsal --rccl-single-rank) every graph is recorded from a sample batch
+BEFORE the RCCL communicator is created (GroupedTeacherKDStep.prepare), then the parameters are
+broadcast and the timed steps exchange their gradients between the step's two graphs.
 
 `python bench.py --gpus N` without WORLD_SIZE in the environment launches its own N ranks (one child process per
 GPU, started before this process makes any GPU call; rank 0's line is passed through, a failing rank fails the run).
@@ -93,10 +96,10 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     p.add_argument("--teacher-group", type=int, default=0,
                    help="pipelined launch only: run the frozen teacher over the batches of this many consecutive steps at "
-                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step; 0 (default) = 3 on one "
-                        "rank, 1 when a gradient exchange is active (measured with the one-rank RCCL rehearsal: the "
-                        "all-reduce beside a free-running teacher stream costs more than the grouping gains, 4730-4800 "
-                        "against 5340-5460 images/s)")
+                        "once (kd6d.graph.GroupedTeacherKDStep); 1 = one teacher forward per step; 0 (default) = 3, "
+                        "except with --exchange overlap under a process group (1): collectives captured inside the step "
+                        "graph need the communicator before the capture, and graphs recorded after an RCCL communicator "
+                        "was created replay 18 %% slower in the grouped mode (DESIGN.md section 7)")
     p.add_argument("--debug-skip-teacher", type=int, default=0,
                    help="timing experiment, INVALID as a result (reported as such): 1 = replay no teacher segment, 2 = every "
                         "second one -- what the student's steps cost without / with half of the teacher beside them")
@@ -303,10 +306,21 @@ def main():
         student.net.fuse_norm = args.fuse_norm in ("student", "both")
     D.SINGLE_RANK_EXCHANGE = bool(args.rccl_single_rank)
     D.EXCHANGE_MODE = args.exchange
-    route = D.init_exchange() if use_pg else "none"      # kd6d_comm_* over librccl (include/kd6d.h)
-    if use_pg:
+    if args.teacher_group == 0:
+        # default: the grouped teacher pass; beside a gradient exchange only in its "between" schedule (a collective
+        # captured INSIDE the step's graph needs the communicator before the capture, which this launch mode pays 18 % for)
+        args.teacher_group = 1 if (use_pg and args.exchange == "overlap") else 3
+    grouped = args.teacher_group > 1 and not args.no_pipeline and not args.no_graph
+
+    def start_exchange():
+        r = D.init_exchange()                   # kd6d_comm_* over librccl (include/kd6d.h)
         D.broadcast_(student.net.store.params, 0)
         student.net.invalidate()
+        return r
+
+    route = "none"
+    if use_pg and not grouped:
+        route = start_exchange()
     base_lr = 1e-3 / world                      # libs/train_libs.py:117
     opt = FusedClipAdamW(student, lr=base_lr, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, base_lr, 10100, pct_start=0.05, cycle_momentum=False,
@@ -322,8 +336,6 @@ def main():
     tune = dict(kv.split("=") for kv in args.tune)
     if "streams" in tune:
         GraphedKDStep.WGRAD_STREAMS = int(tune["streams"])
-    if args.teacher_group == 0:
-        args.teacher_group = 1 if use_pg else 3
     if args.no_graph:
         gstep = None
     else:
@@ -333,6 +345,14 @@ def main():
         else:
             gstep = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=not args.no_pipeline)
     group = getattr(gstep, "group", 1)
+    if use_pg and grouped:
+        # graphs first, communicator second (GroupedTeacherKDStep.prepare): every graph is recorded from a sample batch
+        # before the first RCCL communicator of the process exists; the parameters are broadcast afterwards and the bf16
+        # shadow / dgrad packing the recorded kernels read are refreshed eagerly
+        gstep.prepare(*batches[0])
+        route = start_exchange()
+        student.net.prepare_weights(need_dgrad=True)
+        torch.cuda.synchronize()
     if gstep is not None:
         if "budget_div" in tune:
             student.net.wgrad_cu_budget = int(ops.device_cu_count() / float(tune["budget_div"]))

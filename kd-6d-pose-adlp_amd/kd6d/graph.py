@@ -668,7 +668,8 @@ class GroupedTeacherKDStep(GraphedKDStep):
             for _ in range(self.warmup):
                 for s in range(T):
                     self._student_body(s)
-                    self._exchange()
+                    # (no gradient exchange here: these steps are thrown away with the snapshot, and no RCCL communicator
+                    #  may come to life before the graphs exist -- see prepare())
                     self.opt.advance()
                     self.opt.launch(device_schedule=True)
                     self._count_opt_step()
@@ -749,6 +750,31 @@ class GroupedTeacherKDStep(GraphedKDStep):
             self._sizes = getattr(images, "sizes", None)
             self._build_sides(images.tensors if hasattr(images, "tensors") else images, tgt)
         return tgt
+
+    def prepare(self, images, tgt):
+        """Capture every graph NOW from a sample batch, leaving the pipeline empty and the training state untouched.
+
+        For data-parallel runs: call it BEFORE the first RCCL communicator of the process is created (before
+        kd6d.libs.distributed.init_exchange() and before any torch.distributed collective on the device).  Measured in the
+        one-rank rehearsal: graphs instantiated after ncclCommInitRank has run replay 18 % slower in this launch mode
+        (5115-5180 against 6216-6290 images/s; destroying the communicator again does not bring it back, creating it after
+        the capture costs nothing; which stream the teacher replays on, the number of weight-gradient streams or the
+        communicator's channel count make no difference).  Without prepare() the graphs are captured by the first calls
+        that need them, as before."""
+        tgt = self._prepare(images, tgt)
+        if self.g_student is not None and self.g_teacher is not None:
+            return
+        if self.pending_steps:
+            raise RuntimeError("GroupedTeacherKDStep.prepare(): call it before the first batch is fed")
+        for _ in range(self.group):
+            self._load_group(images, tgt)
+        self._rotate()                          # PASS <- LOAD
+        self._teacher_segments(self.group)      # records the teacher's graphs (and runs them once: cells of the sample)
+        self._rotate()                          # CURRENT <- PASS
+        self._ensure_captured()                 # the student's graphs; snapshot / restore around their warm-up steps
+        torch.cuda.synchronize()
+        self.n_loaded = self.p_valid = self.t_pos = self.c_valid = self.c_pos = 0
+        self.teacher_passes = 0
 
     def flush(self):
         """Train on ONE batch that is still waiting for its student step, without consuming a new one; None when

@@ -51,3 +51,25 @@ def test_bench_self_launch_reports_missing_gpus(gpu_device):
     assert r.returncode != 0
     assert ("%d GPUs needed, %d visible" % (want, have)) in (r.stderr + r.stdout), (r.stdout[-1000:], r.stderr[-1000:])
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_one_rank_rccl_rehearsal_takes_the_grouped_mode(gpu_device):
+    """The N > 1 code path on one rank (process group, kd6d communicator, parameter broadcast, the all-reduce between the
+    two graphs of every step): bench.py records every graph from a sample batch BEFORE the communicator exists
+    (GroupedTeacherKDStep.prepare) and keeps the grouped teacher pass; --exchange overlap (collectives captured inside
+    the step graph) falls back to one teacher forward per step."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    for extra, group, graphs in (((), 3, 2), (("--exchange", "overlap"), 1, 1)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                            "--rccl-single-rank", "--no-cpu-baseline", "--no-secondary", "--no-launch-events"] + list(extra),
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        cfg = d["config"]
+        assert d["finite"] is True and d["barrier_timeouts"] == 0 and d["rccl_ranks"] == 1
+        assert cfg["exchange"].startswith("kd6d_comm") and cfg["teacher_group"] == group, cfg
+        assert ("%d graph" % graphs) in cfg["launch"], cfg["launch"]

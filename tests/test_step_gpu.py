@@ -534,6 +534,54 @@ def test_grouped_teacher_matches_sequential_steps(gpu_device, group):
     assert gs.pending_steps == 1
 
 
+def test_grouped_teacher_prepare_leaves_training_state_untouched(gpu_device):
+    """GroupedTeacherKDStep.prepare(sample batch) records every graph up front (what a data-parallel run does before its
+    first RCCL communicator exists): afterwards no optimiser step has been taken, parameters / optimiser moments / BatchNorm
+    buffers are bitwise what they were, the pipeline is empty, and the first trained batch reports the loss the eager step
+    reports for it at the initial weights."""
+    from kd6d.graph import GroupedTeacherKDStep
+    from kd6d.kd_losses import PackedTargets
+    from kd6d.libs.poses import ImageList
+    from kd6d.optim import FusedClipAdamW
+    from kd6d.synthetic import make_batch
+    dev = gpu_device
+    B, crop, group = 2, 64, 2
+    batches = []
+    for i in range(5):
+        images, targets = make_batch(B, 60 + i, crop=crop)
+        batches.append((ImageList(images.tensors.to(dev), images.sizes), PackedTargets(targets, dev)))
+    rows = B * sum((crop // 8 // 2 ** i) ** 2 for i in range(4))
+    keys = torch.rand(rows, generator=torch.Generator().manual_seed(3)).to(dev)
+    teacher = build("darknet53", "fp32", 2, dev, [1.0] + [-6.0] * 14).eval()
+    student = build("darknet_tiny_h", "fp32", 1, dev).train()
+    student._debug_keys = keys
+    opt = FusedClipAdamW(student, lr=1e-4)
+    st = student.net.store
+    before = (st.params.clone(), st.bufs.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), student._nbt.clone())
+    gs = GroupedTeacherKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=group)
+    gs.prepare(*batches[4])                                   # a sample that is NOT the first training batch
+    torch.cuda.synchronize()
+    assert opt.steps == 0 and gs.pending_steps == 0 and gs.teacher_passes == 0
+    assert gs.g_student is not None and gs.g_teacher is not None and len(gs.segment_ms) == group
+    after = (st.params, st.bufs, opt.exp_avg, opt.exp_avg_sq, student._nbt)
+    for a, b in zip(before, after):
+        assert torch.equal(a, b)
+    gs.prepare(*batches[4])                                   # idempotent
+    # the eager step's losses for batch 0 at the (untouched) initial weights, on a copy of the student
+    twin = build("darknet_tiny_h", "fp32", 1, dev).train()
+    twin.load_state_dict(student.state_dict())
+    twin._debug_keys = keys
+    with torch.no_grad():
+        pred_t = teacher(batches[0][0], targets=batches[0][1], is_teacher=True)
+    _, want = twin(batches[0][0], targets=batches[0][1], pred_t=pred_t)
+    want = [float(want[k].detach()) for k in ("loss_cls", "loss_reg", "loss_kd")]
+    out = [gs(*batches[i % 4]) for i in range(2 * group + 1)]
+    assert all(o is None for o in out[:2 * group]) and out[-1] is not None
+    got = [float(out[-1][k]) for k in ("loss_cls", "loss_reg", "loss_kd")]
+    np.testing.assert_allclose(got, want, rtol=1e-3)
+    assert opt.steps == 1
+
+
 def test_replayed_step_draws_new_sampling_keys(gpu_device):
     """Without pinned keys the replayed step draws its SSC sampling keys on the device from (seed, step counter, cell):
     every replay sees new keys in [0, 1), the same seed reproduces the sequence, and the step stays finite."""

@@ -169,8 +169,9 @@ if __name__ == "__main__":
         group = int(cfg["RUNTIME"].get("TEACHER_GROUP", 1))
         if launch == "pipeline" and group > 1:
             if cfg["RUNTIME"]["DISTRIBUTED"] and get_rank() == 0:
-                print("note: --teacher_group %d beside a gradient exchange measured SLOWER than --teacher_group 1 in the "
-                      "one-rank rehearsal (DESIGN.md section 7); bench.py takes group 1 whenever a process group is alive" % group)
+                print("note: --teacher_group %d with more than one rank: hipGraphs recorded after an RCCL communicator was "
+                      "created replay ~18 %% slower in this launch mode (DESIGN.md section 7); this script creates its "
+                      "communicator first -- bench.py shows the other order (GroupedTeacherKDStep.prepare)" % group)
             # the teacher over the batches of `group` steps in one pass (2 * group batches in flight)
             gstep = GroupedTeacherKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd, group=group)
         else:
