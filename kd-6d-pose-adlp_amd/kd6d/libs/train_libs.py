@@ -51,7 +51,8 @@ def build_model(cfg, posemodule, device="cuda"):
                                max_norm=cfg["SOLVER"].get("GRAD_CLIP", 1.0))
     scheduler = optim.lr_scheduler.OneCycleLR(optimizer, base_lr, cfg["SOLVER"]["MAX_ITER"] + 100, pct_start=0.05,
                                               cycle_momentum=False, anneal_strategy="linear")
-    if cfg["RUNTIME"].get("DISTRIBUTED", False):
+    if cfg["RUNTIME"].get("DISTRIBUTED", False) and not cfg["RUNTIME"].get("DEFER_BROADCAST", False):
+        # (DEFER_BROADCAST: train_kd.py broadcasts after the step's graphs have been recorded, see there)
         D.broadcast_(model.net.store.params, 0)
         D.broadcast_(model.net.store.bufs, 0)
         model.net.invalidate()
@@ -108,7 +109,8 @@ def build_model_teacher(cfg, posemodule, device):
     model = posemodule(cfg, build_backbone(cfg["MODEL"]["BACKBONE"]))
     _load_weights(model, cfg["RUNTIME"].get("WEIGHT_FILE", ""))
     model = model.to(device)
-    if cfg["RUNTIME"].get("DISTRIBUTED", False):
+    if cfg["RUNTIME"].get("DISTRIBUTED", False) and not cfg["RUNTIME"].get("DEFER_BROADCAST", False):
+        # (DEFER_BROADCAST: train_kd.py broadcasts after the step's graphs have been recorded, see there)
         D.broadcast_(model.net.store.params, 0)
         D.broadcast_(model.net.store.bufs, 0)
         model.net.invalidate()

@@ -115,12 +115,20 @@ if __name__ == "__main__":
         from kd6d import ops
         ops.set_option("bn.onepass", 0)
         ops.set_option("gn.onepass", 0)
+    # Data-parallel + grouped teacher pass: the step's hipGraphs are recorded BEFORE the process's first RCCL communicator
+    # exists (graphs instantiated after ncclCommInitRank replay ~18 % slower in that launch mode) --
+    # no barrier, no communicator and no parameter broadcast until GroupedTeacherKDStep.prepare() has run, further down.
+    # (The overlapped exchange captures its collectives inside the step graph and needs the communicator first.)
+    graphs_first = (cfg["RUNTIME"]["DISTRIBUTED"] and cfg["RUNTIME"].get("LAUNCH") == "pipeline"
+                    and int(cfg["RUNTIME"].get("TEACHER_GROUP", 1)) > 1 and cfg["RUNTIME"].get("EXCHANGE", "between") == "between")
+    cfg["RUNTIME"]["DEFER_BROADCAST"] = cfg_t["RUNTIME"]["DEFER_BROADCAST"] = graphs_first
     if cfg["RUNTIME"]["DISTRIBUTED"]:
         torch.distributed.init_process_group(backend="nccl", init_method="env://")
-        synchronize()
         from kd6d.libs import distributed as _D
         _D.EXCHANGE_MODE = cfg["RUNTIME"].get("EXCHANGE", "between")
-        print("gradient exchange: " + init_exchange())      # kd6d_comm_* over librccl (include/kd6d.h)
+        if not graphs_first:
+            synchronize()
+            print("gradient exchange: " + init_exchange())      # kd6d_comm_* over librccl (include/kd6d.h)
 
     if cfg["RUNTIME"]["SYNTHETIC"]:
         train_loader = synthetic_loader(cfg, device)
@@ -168,15 +176,33 @@ if __name__ == "__main__":
         from kd6d.graph import GraphedKDStep, GroupedTeacherKDStep
         group = int(cfg["RUNTIME"].get("TEACHER_GROUP", 1))
         if launch == "pipeline" and group > 1:
-            if cfg["RUNTIME"]["DISTRIBUTED"] and get_rank() == 0:
-                print("note: --teacher_group %d with more than one rank: hipGraphs recorded after an RCCL communicator was "
-                      "created replay ~18 %% slower in this launch mode (DESIGN.md section 7); this script creates its "
-                      "communicator first -- bench.py shows the other order (GroupedTeacherKDStep.prepare)" % group)
+            if cfg["RUNTIME"]["DISTRIBUTED"] and not graphs_first and get_rank() == 0:
+                print("note: --teacher_group %d with --exchange overlap: the communicator has to exist before the step is "
+                      "recorded, and hipGraphs recorded after it replay ~18 %% slower in this launch mode (DESIGN.md "
+                      "section 7); --exchange between records the graphs first" % group)
             # the teacher over the batches of `group` steps in one pass (2 * group batches in flight)
             gstep = GroupedTeacherKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd, group=group)
         else:
             gstep = GraphedKDStep(model_t, model, optimizer, (w_cls, w_reg, w_kd), cfg_kd=cfg_kd,
                                   pipeline=(launch == "pipeline"))
+    if graphs_first:
+        # graphs first (from the first training batch, which is then fed as usual), communicator second, then what the
+        # model builders deferred: rank 0's weights and buffers to every rank, and an eager refresh of what the recorded
+        # kernels read of them (bf16 shadow, dgrad packing)
+        import itertools
+        from kd6d.libs import distributed as _D
+        train_iter = iter(train_loader)
+        first = next(train_iter)
+        gstep.prepare(first[0], first[1])
+        synchronize()
+        print("gradient exchange: " + init_exchange())
+        for m in (model_t, model):
+            _D.broadcast_(m.net.store.params, 0)
+            _D.broadcast_(m.net.store.bufs, 0)
+        model.net.invalidate()
+        model.net.prepare_weights(need_dgrad=True)
+        torch.cuda.synchronize()
+        train_loader = itertools.chain([first], train_iter)
     MAX_ITER = cfg["SOLVER"]["MAX_ITER"]
     pipelined = gstep is not None and gstep.pipeline
     for idx, (images, targets, _) in enumerate(train_loader):
