@@ -36,7 +36,8 @@ The single JSON line carries, besides the contract fields:
   secondary    -- (N=1, default workload only) 20-step timings of the other BASELINE configurations, each run by this
                   same script in a child process AFTER the headline's timed region: config 4's per-GPU shard
                   (--workload linemod13), full 480x640 frames (--frame full640), one teacher forward per step
-                  (--teacher-group 1), strictly sequential steps (--no-pipeline) and the dense 16-D OT of config 5 (--workload dense16d).  The headline does not
+                  (--teacher-group 1), strictly sequential steps (--no-pipeline), the one-rank rehearsal of the data-parallel
+                  path (--rccl-single-rank) and the dense 16-D OT of config 5 (--workload dense16d).  The headline does not
                   depend on them: a failing child is reported inside its entry.
 """
 import argparse
@@ -660,6 +661,9 @@ SECONDARY = [          # (name, BASELINE.json config it stands for, extra flags)
                        "rounds 1-2)", ["--teacher-group", "1"]),
     ("no_pipeline", "config 2, strictly sequential steps (teacher and student of the SAME batch in one step)", ["--no-pipeline"]),
     ("dense16d", "config 5: dense 16-D OT over a 128x128 cell grid", ["--workload", "dense16d"]),
+    ("rccl_rehearsal_1rank", "config 3's code path on ONE rank: process group, graphs recorded before the RCCL communicator, "
+                             "parameter broadcast, the all-reduce between the two graphs of every step (no second GPU: what "
+                             "the exchange costs beside the grouped pass, not scaling)", ["--rccl-single-rank"]),
 ]
 
 
@@ -673,8 +677,15 @@ def secondary_runs(args):
                str(args.batch), "--no-cpu-baseline", "--no-secondary", "--no-launch-events"] + flags
         entry = {"name": name, "what": what, "flags": " ".join(flags)}
         t0 = time.perf_counter()
+        env = None
+        if "--rccl-single-rank" in flags:          # a one-rank process group of its own
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 entry.update(ok=False, rc=r.returncode, error=(r.stderr or "")[-400:])
