@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KD6D_ABI_VERSION 7
+#define KD6D_ABI_VERSION 8
 
 enum { KD6D_BF16 = 0, KD6D_F32 = 1 };
 enum { KD6D_ACT_NONE = 0, KD6D_ACT_LEAKY = 1, KD6D_ACT_RELU = 2 };
@@ -66,6 +66,38 @@ typedef struct kd6d_conv_geom {
 const char* kd6d_last_error(void);
 int kd6d_abi_version(void);
 
+/* ---- reproducible reductions (ABI v8) -------------------------------------------------------------------------
+ * Every sum this library forms ACROSS workgroups -- normalisation statistics, the sums of the normalisation
+ * backwards, weight / bias / scale gradients, loss values, the gradient norm -- is accumulated with 64-bit INTEGER
+ * atomics on a fixed-point image of the fp32 addends (csrc/kd6d_det.h), never with floating-point atomics: integer
+ * addition is associative, so two executions of the same launch sequence on the same inputs give BITWISE identical
+ * results whatever order the hardware retires the atomics in (the reference's CPU step is deterministic too:
+ * train_kd.py:137-140 is one single-threaded backward).
+ *   kd6d_acc: one accumulator, two words; value = hi * 2^(47-E) + lo * 2^-E with E = KD6D_ACC_ACT for statistics of
+ *   activations and loss values, KD6D_ACC_GRAD for everything summed in the reverse sweep.  Zero-initialised by the
+ *   caller (the engine zeroes its whole statistics arena once per step), only ever added to; a non-finite addend
+ *   poisons it (the value reads as NaN).  Arrays of kd6d_acc are INTERLEAVED {lo, hi} per element.
+ *   Gradient outputs (dw / dbias of kd6d_conv2d_wgrad, dgamma / dbeta of kd6d_gn_relu_bwd, dseg_scale of
+ *   kd6d_loss_backward) use the PLANAR layout instead: `int64_t* acc` + `acc_hi_stride`, word lo of element i at
+ *   acc[i], word hi at acc[i + acc_hi_stride] (a wave's 64 lo words are then contiguous: tile flushes are 2-4x
+ *   faster than interleaved).  The engine keeps ONE such accumulator image of its flat gradient bucket (lo plane then
+ *   hi plane) and turns it into fp32 gradients once per step with kd6d_grad_acc_resolve.
+ * kd6d_acc_read: out[i] (=, or += when accumulate != 0) value(acc[i]) for n interleaved accumulators of class
+ * `kind`; clear != 0 zeroes them afterwards.  kd6d_grad_acc_resolve: for every region r of desc_dev (int64 triples
+ * {first element, element count, first workgroup}; total_blocks workgroups of 1024 elements each, regions in ascending
+ * block order) grads[e] += value(acc planar element e, class KD6D_ACC_GRAD) and the accumulator is cleared -- one
+ * launch at the end of the reverse sweep. */
+typedef struct kd6d_acc { int64_t lo, hi; } kd6d_acc;
+/* Workspace of a launch that reduces to ONE fp32 scalar (kd6d_focal_fwd, kd6d_student_points' loss_reg, kd6d_sumsq):
+ * 32 bytes, pre-zeroed; the launch's LAST workgroup converts the fixed-point total and WRITES the scalar (the running
+ * total if the workspace is reused without zeroing -- the "+=" of earlier ABI versions); arrivals is left at 0. */
+typedef struct kd6d_scalar_ws { int64_t lo, hi; uint32_t arrivals; uint32_t reserved[3]; } kd6d_scalar_ws;
+#define KD6D_ACC_ACT 32
+#define KD6D_ACC_GRAD 52
+int kd6d_acc_read(kd6d_acc* acc, int64_t n, int kind, float* out, int accumulate, int clear, void* stream);
+int kd6d_grad_acc_resolve(const int64_t* desc_dev, int n_regions, int total_blocks, int64_t* acc,
+                          int64_t acc_hi_stride, float* grads, void* stream);
+
 /* Pair bracket: between _begin and _end, convolutions that resolve to the 3x3 "halo patch" kernel (forward or
  * data gradient) are recorded instead of launched; _end issues two recorded launches of the same kernel variant,
  * geometry and stream as ONE launch (workgroups of both convolutions in one grid), anything else one by one, in
@@ -83,8 +115,8 @@ int kd6d_conv2d_pair_pending(void);   /* launches recorded so far in the open br
  *   y = act((conv(x) * ch_scale[c] + ch_shift[c]) * seg_scale[level]) + residual
  * ch_scale/ch_shift/seg_scale/residual may be NULL.  out_f32 != 0 writes fp32
  * regardless of dtype.
- * stats (optional, caller-zeroed): statistics of the stored y accumulated by the epilogue with fp32
- * atomics, so that the normalisation that follows needs no separate reduction pass:
+ * stats (optional, caller-zeroed accumulators, class KD6D_ACC_ACT): statistics of the stored y accumulated by the
+ * epilogue, so that the normalisation that follows needs no separate reduction pass:
  *   stats_groups == 0: {sum[cout], sumsq[cout]}           (BatchNorm batch statistics, = kd6d_colstats)
  *   stats_groups  > 0: {sum, sumsq} per (level, image, group), the layout kd6d_gn_relu_fwd consumes.
  * workspace (optional device scratch, any contents): lets layers with few output tiles and a long K run
@@ -92,7 +124,7 @@ int kd6d_conv2d_pair_pending(void);   /* launches recorded so far in the open br
 int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x,
                     const void* w, void* y, const float* ch_scale,
                     const float* ch_shift, int act, const void* residual,
-                    const float* seg_scale, int out_f32, float* stats, int stats_groups,
+                    const float* seg_scale, int out_f32, kd6d_acc* stats, int stats_groups,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Convolution (+ bias) with the normalisation and activation that follow it fused into its epilogue: one launch
@@ -105,7 +137,7 @@ int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x,
  *   kind      KD6D_NORM_GROUP | KD6D_NORM_BATCH;  groups: GroupNorm groups (4 or 8 channels per group)
  *   y         (rows_out, cout) in `dtype`: act(norm(conv(x) + bias))
  *   raw_out   optional (rows_out, cout) fp32: conv(x) + bias, what the backward pass of the normalisation reads
- *   stats     pre-zeroed fp32: GROUP nseg*batch*groups*2 (the layout kd6d_gn_relu_bwd consumes);
+ *   stats     pre-zeroed accumulators: GROUP nseg*batch*groups*2 (the layout kd6d_gn_relu_bwd consumes);
  *             BATCH KD6D_BN_FUSED_REPLICAS*2*cout (private layout)
  *   counters  pre-zeroed 32-bit words: GROUP nseg*batch*KD6D_NORM_MAX_CTILES; BATCH KD6D_BARRIER_WORDS
  *   BATCH only: momentum, running_mean / running_var (updated in place), save_mean / save_invstd (outputs for
@@ -127,7 +159,7 @@ typedef struct kd6d_conv_norm {
   const float* gamma;
   const float* beta;
   void* y;
-  float* stats;
+  kd6d_acc* stats;
   unsigned int* counters;
   float* running_mean;
   float* running_var;
@@ -147,7 +179,7 @@ int kd6d_conv2d_fwd_norm(const kd6d_conv_geom* g, int dtype, const void* x, cons
  * running statistics are written by this launch, and z_out (optional, (rows_in, cin) in `dtype`) receives the
  * activation the weight gradient of THIS convolution reads.  bn != NULL needs a 1x1 or 3x3 stride-1 'same' convolution. */
 typedef struct kd6d_bn_in {
-  const float* sums;
+  const kd6d_acc* sums;
   int32_t replicas;
   int32_t act;
   float eps;
@@ -160,21 +192,22 @@ typedef struct kd6d_bn_in {
   float* save_invstd;
 } kd6d_bn_in;
 int kd6d_conv2d_fwd_block(const kd6d_conv_geom* g, int dtype, const void* x, const kd6d_bn_in* bn, void* z_out,
-                          const void* w, float* y_raw, float* stats, int stats_replicas, void* stream);
+                          const void* w, float* y_raw, kd6d_acc* stats, int stats_replicas, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  wt is the dgrad packing wt[cin][ky][kx][cout]
  * produced by kd6d_pack_dgrad_weights.  accumulate != 0 adds into dx. */
 int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void* dy,
                       const void* wt, void* dx, int accumulate, void* stream);
 
-/* dw[cout][ky][kx][cin] += sum_pixels dy (x) x   (fp32 atomics, dw pre-zeroed
- * or holding a running sum).  dbias (optional): dbias[cout] += sum_pixels dy, the bias gradient of
- * the same layer, taken from the dY tiles the kernel stages anyway.
+/* dw[cout][ky][kx][cin] += sum_pixels dy (x) x, into PLANAR gradient accumulators (class KD6D_ACC_GRAD, see
+ * "reproducible reductions": dw_acc[i] / dw_acc[i + acc_hi_stride]; pre-zeroed or holding a running sum).
+ * dbias_acc (optional): += sum_pixels dy, the bias gradient of the same layer, taken from the dY tiles the kernel
+ * stages anyway (same layout and stride).
  * cu_budget: how many compute units this launch should aim to fill (0 = the whole device).  The pixel
  * axis is split over workgroups and every split ends in an atomic flush of its dW tile, so a caller that
  * keeps k weight gradients in flight on k streams passes CUs/k: same k-loop work, 1/k of the flushes. */
-int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x,
-                      const void* dy, float* dw, float* dbias, int cu_budget, void* stream);
+int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy, int64_t* dw_acc,
+                      int64_t* dbias_acc, int64_t acc_hi_stride, int cu_budget, void* stream);
 
 /* wt[cin][ky][kx][cout] <- w[cout][ky][kx][cin] for n_layers layers in one
  * launch.  desc_dev: int32[n_layers*6] = {w_off, wt_off, cout, cin, ksize,
@@ -288,24 +321,24 @@ int kd6d_mark(unsigned long long* slot, void* stream);
 
 /* ---- normalisation / pooling (HBM-bound, 16-B granules) ------------------------------------
  * BatchNorm2d(train)+LeakyReLU of ConvBlock (backbone/common.py:316-324): batch statistics by
- * kd6d_colstats (per-channel sum / sum of squares, fp32 atomics into pre-zeroed buffers), then
+ * kd6d_colstats (per-channel sum / sum of squares into pre-zeroed accumulators, class KD6D_ACC_ACT), then
  * kd6d_bn_train_fwd normalises, updates running stats (momentum 0.1, unbiased var) and saves
  * mean / invstd for the backward pair.  x_f32 != 0: the pre-normalisation tensor x is fp32 while
  * activations/gradients are `dtype` (keeps (x - mean) free of bf16 cancellation error).
- * Backward pair: sum_dy / sum_dy_xhat are `replicas` (1..64) rows of C floats each, pre-zeroed; the
+ * Backward pair: sum_dy / sum_dy_xhat are `replicas` (1..64) rows of C accumulators (KD6D_ACC_GRAD) each, pre-zeroed; the
  * reduction's workgroups spread their per-channel atomics over the rows (same-address atomics retire
  * serially, ~27 ns each, and this kernel needs hundreds of workgroups), the apply kernel sums the rows. */
-int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum, float* sumsq, void* stream);
-int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows, int C, const float* sum,
-                      const float* sumsq, const float* gamma, const float* beta, float eps, float momentum,
+int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, kd6d_acc* sum, kd6d_acc* sumsq, void* stream);
+int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows, int C, const kd6d_acc* sum,
+                      const kd6d_acc* sumsq, const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                       int act, void* stream);
 int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, const void* dz, int64_t rows, int C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                             int act, float* sum_dy, float* sum_dy_xhat, int replicas, void* stream);
+                             int act, kd6d_acc* sum_dy, kd6d_acc* sum_dy_xhat, int replicas, void* stream);
 int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
                             const float* mean, const float* invstd, const float* gamma, const float* beta,
-                            int act, const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
+                            int act, const kd6d_acc* sum_dy, const kd6d_acc* sum_dy_xhat, float* dgamma,
                             float* dbeta, int replicas, void* stream);
 
 /* BN(train) + activation + MaxPool2d(2,2) in one pass: the last ConvBlock of a darknet-tiny stage and the pool
@@ -315,12 +348,12 @@ int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz,
  * window order (MaxPool2d's rule).  Statistics, saved mean / invstd, replicas and workspaces as in the unpooled
  * entry points above; kd6d_bn_pool_train_bwd runs the reduction and the apply pass. */
 int kd6d_bn_pool_train_fwd(int dtype, int x_f32, const void* x, void* y, int B, int H, int W, int C,
-                           const float* sum, const float* sumsq, const float* gamma, const float* beta, float eps,
+                           const kd6d_acc* sum, const kd6d_acc* sumsq, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, float* save_mean,
                            float* save_invstd, int act, void* stream);
 int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, void* dx, int B, int H, int W,
                            int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                           int act, float* sum_dy, float* sum_dy_xhat, unsigned int* counter, float* dgamma,
+                           int act, kd6d_acc* sum_dy, kd6d_acc* sum_dy_xhat, unsigned int* counter, float* dgamma,
                            float* dbeta, int replicas, void* stream);
 
 #define KD6D_BARRIER_WORDS 32
@@ -334,28 +367,30 @@ int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, 
  * option bn.onepass = 0: the reduce + apply pair above.  kd6d_barrier_timeouts(): number of barrier waits that gave up (must stay 0). */
 int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
                       const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                      float* sum_dy, float* sum_dy_xhat, unsigned int* counter, float* dgamma, float* dbeta,
+                      kd6d_acc* sum_dy, kd6d_acc* sum_dy_xhat, unsigned int* counter, float* dgamma, float* dbeta,
                       int replicas, void* stream);
 int kd6d_barrier_timeouts(void);
 
 /* GroupNorm(groups)+ReLU of the PoseHead towers (models/model.py:395-417) over a multi-level
- * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 floats per
+ * tensor; level_hw_host[l] = H*W of level l (HOST array).  stats: 2 accumulators (KD6D_ACC_ACT) per
  * (level, image, group) = RAW sums {sum x, sum x^2} (mean/rstd are derived by the consumers, which is
- * why the backward takes eps too); gsum_ws (backward): 2*nseg*batch*groups floats of sums followed by
+ * why the backward takes eps too); gsum_ws (backward): 2*nseg*batch*groups accumulators (KD6D_ACC_GRAD) followed by
  * nseg*batch 32-bit barrier counters -- the backward is ONE launch whose workgroups of a (level, image) meet at
  * an in-kernel barrier (see kd6d_bn_train_bwd; option gn.onepass = 0: the reduce + apply pair).
  * flags: bit 0 (KD6D_GN_STATS_READY) -- stats were already accumulated by kd6d_conv2d_fwd(..., stats,
  * groups): skip the reduction pass; bit 1 (KD6D_GN_WS_ZEROED) -- the caller zeroed stats (fwd, when not
  * ready) / gsum_ws (bwd) itself (e.g. one memset of a whole scratch arena per step): skip the memset node.
- * Requires C/groups >= granule/2 (a 16-B granule spans <= 2 groups). */
+ * dgamma / dbeta (backward, optional): PLANAR gradient accumulators with stride acc_hi_stride (see "reproducible
+ * reductions").  Requires C/groups >= granule/2 (a 16-B granule spans <= 2 groups). */
 #define KD6D_GN_STATS_READY 1
 #define KD6D_GN_WS_ZEROED 2
 int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host, int nseg, int batch,
-                     int C, int groups, const float* gamma, const float* beta, float eps, float* stats,
+                     int C, int groups, const float* gamma, const float* beta, float eps, kd6d_acc* stats,
                      int flags, void* stream);
 int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, const int32_t* level_hw_host,
                      int nseg, int batch, int C, int groups, const float* gamma, const float* beta, float eps,
-                     const float* stats, float* gsum_ws, float* dgamma, float* dbeta, int flags, void* stream);
+                     const kd6d_acc* stats, kd6d_acc* gsum_ws, int64_t* dgamma_acc, int64_t* dbeta_acc,
+                     int64_t acc_hi_stride, int flags, void* stream);
 /* Two GroupNorm+ReLU backwards of identical geometry (the cls and the pose tower layer of PoseHead,
  * models/model.py:438-451) as ONE launch of the in-kernel-barrier form: alone each is 170 four-wave workgroups on
  * 256 CUs.  Same arguments as kd6d_gn_relu_bwd, the per-tensor ones in an item each; falls back to two launches
@@ -366,14 +401,14 @@ typedef struct kd6d_gn_item {
   void* dx;
   const float* gamma;
   const float* beta;
-  const float* stats;
-  float* gsum_ws;
-  float* dgamma;
-  float* dbeta;
+  const kd6d_acc* stats;
+  kd6d_acc* gsum_ws;
+  int64_t* dgamma;      /* planar gradient accumulators (acc_hi_stride of the call) */
+  int64_t* dbeta;
 } kd6d_gn_item;
 int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a, const kd6d_gn_item* b,
-                          const int32_t* level_hw_host, int nseg, int batch, int C, int groups, float eps, int flags,
-                          void* stream);
+                          const int32_t* level_hw_host, int nseg, int batch, int C, int groups, float eps,
+                          int64_t acc_hi_stride, int flags, void* stream);
 
 /* MaxPool2d(2,2) (backbone/darknet.py:94-97), nearest-x2 upsample + add (models/model.py:75-78)
  * and its adjoint, ReLU / ReLU-backward / add (mode 0/1/2), NCHW fp32 image -> padded NHWC. */
@@ -411,12 +446,14 @@ int kd6d_sinkhorn_max_points(void);
  * kd6d_ssc_assign      <- losses/loss.py:164-268; per-image inputs are padded to KD6D_MAX_GT
  *   instances; keys (rows) are caller-supplied uniform randoms (the n smallest in-mask keys per
  *   level are the reference's randperm(...)[:n]).  labels (rows): -1 ignore, 0 bg, c+1.
- * kd6d_focal_fwd/bwd   <- losses/loss.py:20-40 (sum reduction; bwd writes ALL of dcls).
+ * kd6d_focal_fwd/bwd   <- losses/loss.py:20-40 (sum reduction into *loss through loss_ws, see kd6d_scalar_ws; bwd
+ *   writes ALL of dcls).
  * kd6d_student_points  <- losses/kd_loss.py:40-71,152: decoded full-frame keypoints of the
- *   positive cells (normalised by frame_w/h into xs), OT weights alpha, loss_reg (+=) and its
+ *   positive cells (normalised by frame_w/h into xs), OT weights alpha, loss_reg (through loss_reg_ws) and its
  *   gradient w.r.t. the full-frame points.
  * kd6d_kd_mean         <- kd_loss.py:99-103.
- * kd6d_loss_backward   <- autograd of the above into dcls (+=) / dreg (positive rows only). */
+ * kd6d_loss_backward   <- autograd of the above into dcls (+=) / dreg (positive rows only); dseg_scale_acc (optional):
+ *   the gradient of PoseHead.scales, PLANAR gradient accumulators (one per level) with stride acc_hi_stride. */
 int kd6d_teacher_select(const kd6d_levels* levels, const float* cls, const float* reg,
                         const float* bbox_trans, float threshold, float positive_num, float positive_lambda,
                         int cap, float frame_w, float frame_h, int32_t* t_cnt, float* t_kp, float* t_score,
@@ -437,15 +474,15 @@ int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int mask_h, in
                     float positive_lambda, int cap, int32_t* labels, int32_t* pos_cnt, int32_t* pos_row,
                     int32_t* pos_gt, void* stream);
 int kd6d_focal_fwd(const float* cls, const int32_t* labels, int rows, float gamma, float alpha, float* loss,
-                   void* stream);
+                   kd6d_scalar_ws* loss_ws, void* stream);
 int kd6d_focal_bwd(int dtype, const float* cls, const int32_t* labels, int rows, float gamma, float alpha,
                    const float* weight, void* dcls, void* stream);
 int kd6d_student_points(const kd6d_levels* levels, const float* cls, const float* reg, const int32_t* pos_cnt,
                         const int32_t* pos_row, const int32_t* pos_gt, const int32_t* class_ids,
                         const float* kp3d, const float* rot, const float* trans, const float* bbox_trans,
                         const float* diameters, const float* kinv_host, float frame_w, float frame_h, int cap,
-                        float* xs, float* alpha, float* g_reg_xy, float* loss_reg, int32_t* s_start,
-                        void* stream);
+                        float* xs, float* alpha, float* g_reg_xy, float* loss_reg, kd6d_scalar_ws* loss_reg_ws,
+                        int32_t* s_start, void* stream);
 int kd6d_kd_mean(const float* loss_img, const int32_t* valid_img, int n_images, float* loss_kd,
                  int32_t* n_valid, void* stream);
 int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const float* cls, const float* reg,
@@ -453,8 +490,8 @@ int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const float* cls, c
                        const int32_t* class_ids, const float* bbox_trans, const float* g_reg_xy,
                        const float* g_kd_xs, const float* g_kd_alpha, const int32_t* n_valid,
                        const int32_t* valid_img, const float* weights, const float* seg_scale,
-                       float* dseg_scale, float frame_w, float frame_h, int cap, int detach_alpha, void* dcls,
-                       void* dreg, void* stream);
+                       int64_t* dseg_scale_acc, int64_t acc_hi_stride, float frame_w, float frame_h, int cap,
+                       int detach_alpha, void* dcls, void* dreg, void* stream);
 
 /* ---- dense optimal transport (BASELINE config 5: D-dimensional local predictions over a whole cell grid,
  * thousands of points per set; the reference would need geomloss' KeOps backend above 5000^2 pairs).  Same
@@ -483,15 +520,16 @@ int kd6d_dzi_crop(const uint8_t* frames_bgr, const float* masks, int B, int H, i
                   float* bbox_scale, void* stream);
 
 /* ---- optimiser: replaces clip_grad_norm_ + AdamW.step of train_kd.py:138-139 on one flat buffer.
- * kd6d_sumsq accumulates sum(x^2) into *out (pre-zeroed); kd6d_clip_adamw applies
+ * kd6d_sumsq writes sum(x^2) to *out through ws (kd6d_scalar_ws, pre-zeroed: reproducible); kd6d_clip_adamw applies
  * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update
  * (torch.optim.AdamW semantics, step counted from 1) and refreshes the bf16 shadow if given.
- * hyper_dev (optional, 4 floats on the device: lr, 1-beta1^t, sqrt(1-beta2^t), and a fourth that kd6d_set_hyper
- * sets to 0 -- the host keeps its gradient-norm accumulator there, cleared without a launch of its own) overrides lr/step:
+ * hyper_dev (optional, 16 floats on the device, 16-byte aligned: lr, 1-beta1^t, sqrt(1-beta2^t), a fourth that
+ * kd6d_set_hyper sets to 0 -- the host keeps the squared gradient norm there -- and, at floats 8..15, the kd6d_scalar_ws
+ * of kd6d_sumsq, cleared by kd6d_set_hyper as well: no launch of its own) overrides lr/step:
  * it lets the launch sit inside a captured hipGraph while the OneCycle schedule of
  * libs/train_libs.py:120 keeps advancing on the host; kd6d_set_hyper writes it (values travel in
  * the kernel arguments, so the host may run ahead of the device). */
-int kd6d_sumsq(const float* x, int64_t n, float* out, void* stream);
+int kd6d_sumsq(const float* x, int64_t n, float* out, kd6d_scalar_ws* ws, void* stream);
 int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                     const float* gnorm_sq, double max_norm, double lr, double beta1, double beta2, double eps,
                     double weight_decay, int64_t step, const float* hyper_dev, void* bf16_shadow, void* stream);

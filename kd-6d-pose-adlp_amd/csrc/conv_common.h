@@ -8,6 +8,7 @@
 
 #include "kd6d_barrier.h"
 #include "kd6d_common.h"
+#include "kd6d_det.h"
 
 namespace kd6d_detail {
 
@@ -53,7 +54,7 @@ struct ConvParams {
   const float* seg_scale;
   int act;
   int out_f32;
-  float* stats;        // optional fused statistics of the stored values (see conv_epilogue_stats)
+  long long* stats;    // optional fused statistics of the stored values: accumulators {lo, hi} (kd6d_det.h; conv_epilogue_stats)
   int stats_groups;    // 0: per channel {sum[N], sumsq[N]} (BatchNorm); G > 0: {sum, sumsq} per (level, image, group)
   float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
   int nk_split;        // k-steps per split
@@ -75,7 +76,7 @@ struct ConvParams {
   float* bn_running_var;
   // ---- train-mode BatchNorm + activation of the PREVIOUS block applied while this convolution loads its input
   // (conv_igemm_kernel<..., XF = true>; kd6d_conv2d_fwd_bn_in): src is that block's fp32 conv output ----
-  const float* xf_sum;         // xf_replicas rows of {sum[C], sumsq[C]} (what the previous launch's epilogue accumulated)
+  const long long* xf_sum;     // xf_replicas rows of {sum[C], sumsq[C]} accumulators (what the previous launch's epilogue added up)
   const float* xf_gamma;
   const float* xf_beta;
   float* xf_save_mean;         // outputs for the backward pass of the previous block (written by workgroup 0)
@@ -201,22 +202,27 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // Fused normalisation statistics of a conv output (replaces a separate pass over the fp32 tensor).
-// acc holds the FINAL values (what was stored).  Per-channel mode (BatchNorm batch statistics):
-// registers -> 16-lane shuffle -> LDS (one slot per channel of the tile) -> one global atomic per
-// channel and workgroup.  Group mode (GroupNorm): a 16-pixel fragment normally lies inside one
-// (level, image); its 4-channel lane sums are shuffled down to one atomic pair per group, else
-// (tiny levels, several images per fragment) every lane adds its own 4-channel partial.
+// acc holds the FINAL values (what was stored).  Every cross-wave / cross-workgroup addition is either a fixed-order
+// fp32 sum or an integer atomic on a fixed-point image (kd6d_det.h), so the statistics are BITWISE reproducible
+// whatever order waves and workgroups retire in.  The fixed-point conversions sit in two short rolled loops -- not in
+// the unrolled accumulator loops: inlined there (64-128 sites per kernel variant) they tripled the build time.
+//   Per-channel mode (BatchNorm batch statistics): registers -> 16-lane DPP sum -> one LDS slot per (wave row, channel),
+//   plain stores -> a thread per channel adds the WP slots in order -> one global integer atomic per channel and workgroup.
+//   Group mode (GroupNorm): a 16-pixel fragment normally lies inside one (level, image): its 4-channel lane sums are
+//   DPP-summed over the fragment's rows and staged (one entry per writer lane), a rolled loop adds the entries to the LDS
+//   accumulator table [image of the tile][group of the tile]; fragments that straddle images (levels whose H*W is not a
+//   multiple of 16) are staged row by row in 16 more passes.  One flush of the table per workgroup.
+// `red_f32`: the dead staging buffers.
 template <int BP, int BC, int WP, int WC, bool NORM = false>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
-                                                    int m0, int n0, int wp, int wc, int lane, float* red) {
+                                                    int m0, int n0, int wp, int wc, int lane, float* red_f32) {
   constexpr int PI = BP / WP / 16;
   constexpr int CI = BC / WC / 16;
   const int fr = lane & 15;
   const int fq = lane >> 4;
   if (p.stats_groups == 0) {
+    float* slot = red_f32;                 // [WP][2][BC]: every slot is written exactly once
     __syncthreads();                       // staging buffers are dead from here on
-    for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int c = 0; c < CI; ++c) {
       const int nl = wc * (BC / WC) + c * 16 + fq * 4;
@@ -238,11 +244,8 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
         s2[r] = row16_sum(s2[r]);
       }
       if (fr == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(&red[nl + r], s1[r]);
-          atomicAdd(&red[BC + nl + r], s2[r]);
-        }
+        *reinterpret_cast<f32x4_t*>(slot + (wp * 2 + 0) * BC + nl) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4_t*>(slot + (wp * 2 + 1) * BC + nl) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
       }
     }
     __syncthreads();
@@ -253,14 +256,20 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
     for (int i = threadIdx.x; i < 2 * BC; i += blockDim.x) {
       const int which = i / BC, nl = i - which * BC;
       if (n0 + nl < p.N) {
-        float* o = p.stats + (size_t)(rep * 2 + which) * p.N + n0 + nl;
-        if (NORM && p.norm_dst) atomic_add_performed(o, red[i]);
-        else atomicAdd(o, red[i]);
+        float t = slot[which * BC + nl];
+#pragma unroll
+        for (int w = 1; w < WP; ++w) t += slot[(w * 2 + which) * BC + nl];
+        const det_words dw = det_split<KD6D_DET_ACT>(t);
+        long long* o = p.stats + ((size_t)(rep * 2 + which) * p.N + n0 + nl) * 2;
+        if (NORM && p.norm_dst) det_add_words_performed(o, dw.lo, dw.hi);
+        else det_add_words(o, dw.lo, dw.hi);
       }
     }
     return;
   }
-  // ---- group mode: LDS table [image of the tile][group of the tile] -> one full-width flush ----
+  // ---- group mode ----
+  constexpr int NW = WP * WC;
+  constexpr int NENT = NW * PI * CI * 4;   // staged entries of one pass: (wave, fragment q, channel tile c, lane quarter fq)
   const int G = p.stats_groups;
   const int cs = p.stats_cpg_shift;        // 4 or 8 channels per group: a lane's 4 aligned channels share one
   const int GT = BC >> cs;                 // groups touched by this channel tile
@@ -268,43 +277,78 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
   const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
   const int key_lo = key_of(m0);
   const int nkeys = key_of(m_last) - key_lo + 1;
-  const int tab = nkeys * GT * 2;          // <= BP * BC / 2 floats: fits the dead staging buffers
+  const int tab = nkeys * GT * 2;          // accumulators {sum, sumsq} per (key, group): 16 bytes each
+  // LDS image: table | staged entries (float2) | fragment keys | row keys | flag
+  long long* table = reinterpret_cast<long long*>(red_f32);
+  f32x2_t* ent = reinterpret_cast<f32x2_t*>(table + 2 * tab);
+  int* fragkey = reinterpret_cast<int*>(ent + NENT);       // key of a uniform fragment, -1: rows of several images
+  int* rowkey = fragkey + NW * PI;                         // pass j >= 0: key of row j of a non-uniform fragment
+  int* nonuni = rowkey + NW * PI;
+  const int wave = wp * WC + wc;
   __syncthreads();
-  for (int i = threadIdx.x; i < tab; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
-  // a 16-pixel fragment normally lies inside one image: DPP row sum, one writer lane per 4-channel slice;
-  // otherwise (tiny levels, several images per fragment) every lane adds its own partial
+  for (int i = threadIdx.x; i < 2 * tab; i += blockDim.x) table[i] = 0;
+  if (threadIdx.x == 0) *nonuni = 0;
+  // this lane's fragments: row key, uniformity (bit q of umask)
+  int keyq[PI];
+  unsigned umask = 0;
 #pragma unroll
   for (int q = 0; q < PI; ++q) {
     const int m = m0 + wp * (BP / WP) + q * 16 + fr;
     const bool mok = m < p.M;
-    const int key = mok ? key_of(m) - key_lo : 0;
-    const int key0 = __shfl(key, lane & 48, 64);
-    const bool uniform = __all(!mok || key == key0);     // rows past M sit at the tail of the last fragment
+    keyq[q] = mok ? key_of(m) - key_lo : -1;
+    const int key0 = __shfl(keyq[q], lane & 48, 64);
+    if (__all(!mok || keyq[q] == key0)) umask |= 1u << q;       // rows past M sit at the tail of the last fragment
+  }
+  __syncthreads();
+  // pass -1: the uniform fragments, one entry per 4-channel slice (DPP row sum); passes 0..15 (only when the tile holds
+  // a non-uniform fragment): row j of every non-uniform fragment, one entry per lane of that row
+  for (int j = -1; j < 16; ++j) {
+    if (j >= 0) {
+      if (*nonuni == 0) break;             // block-uniform: written before the barrier that ended pass -1
+      __syncthreads();                     // the previous pass has consumed the entries
+    }
 #pragma unroll
-    for (int c = 0; c < CI; ++c) {
-      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
-      const bool ok = mok && n0 + nl < p.N;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = ok ? acc[c][q][r] : 0.f;
-        s1 += v;
-        s2 += v * v;
-      }
-      if (uniform) {
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if (fr == 0 && n0 + nl < p.N) {
-          float* o2 = red + ((key0 * GT + (nl >> cs)) << 1);
-          atomicAdd(o2, s1);
-          atomicAdd(o2 + 1, s2);
+    for (int q = 0; q < PI; ++q) {
+      const bool uni = (umask >> q) & 1u;
+      const bool mine = j < 0 ? (uni && fr == 0) : (!uni && fr == j);
+      if (fq == 0 && wc == 0 && (j < 0 ? fr == 0 : mine)) {
+        if (j < 0) {
+          fragkey[wp * PI + q] = uni ? (keyq[q] < 0 ? 0 : keyq[q]) : -1;
+          if (!uni) *nonuni = 1;
+        } else {
+          rowkey[wp * PI + q] = keyq[q];
         }
-      } else if (ok) {
-        float* o2 = red + ((key * GT + (nl >> cs)) << 1);
-        atomicAdd(o2, s1);
-        atomicAdd(o2 + 1, s2);
       }
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+        const bool ok = keyq[q] >= 0 && n0 + nl < p.N;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = ok ? acc[c][q][r] : 0.f;
+          s1 += v;
+          s2 += v * v;
+        }
+        if (j < 0 && uni) {                // wave-uniform condition: the DPP sum runs with every lane enabled
+          s1 = row16_sum(s1);
+          s2 = row16_sum(s2);
+        }
+        if (mine) ent[((wave * PI + q) * CI + c) * 4 + fq] = f32x2_t{s1, s2};
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NENT; e += blockDim.x) {
+      const int efq = e & 3, ec = (e >> 2) % CI, eq = ((e >> 2) / CI) % PI, ew = (e >> 2) / (CI * PI);
+      const int ewp = ew / WC, ewc = ew - ewp * WC;
+      const int fk = fragkey[ewp * PI + eq];
+      const int key = j < 0 ? fk : (fk < 0 ? rowkey[ewp * PI + eq] : -1);
+      if (key < 0) continue;               // not this pass's kind of fragment, or a row past M
+      const int nl = ewc * (BC / WC) + ec * 16 + efq * 4;
+      const f32x2_t v = ent[e];
+      long long* o2 = table + ((key * GT + (nl >> cs)) << 2);
+      det_add_lds<KD6D_DET_ACT>(o2, v[0]);
+      det_add_lds<KD6D_DET_ACT>(o2 + 2, v[1]);
     }
   }
   __syncthreads();
@@ -314,9 +358,9 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
     const int k = i >> gts, rem = i & (GT * 2 - 1);
     const int gl = rem >> 1;
     if (g_first + gl < G) {
-      float* o = p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1);
-      if (NORM && p.norm_dst) atomic_add_performed(o, red[i]);
-      else atomicAdd(o, red[i]);
+      long long* o = p.stats + (((size_t)(key_lo + k) * G + g_first + gl) * 2 + (rem & 1)) * 2;
+      if (NORM && p.norm_dst) det_add_words_performed(o, table[2 * i], table[2 * i + 1]);
+      else det_add_words(o, table[2 * i], table[2 * i + 1]);
     }
   }
 }
@@ -537,8 +581,14 @@ __device__ __forceinline__ void conv_epilogue_norm(const ConvParams& p, f32x4_t 
     for (int i = tid; i < 2 * BC; i += nthr) {
       const int which = i / BC, nl = i - which * BC;
       float t = 0.f;
-      if (n0 + nl < p.N)
-        for (int r = 0; r < R; ++r) t += load_device_scope(p.stats + (size_t)(r * 2 + which) * p.N + n0 + nl);
+      if (n0 + nl < p.N) {
+        long long lo = 0, hi = 0;           // the replica rows' words as integers (exact), converted once
+        for (int r = 0; r < R; ++r) {
+          const det_words w = det_load_device_scope(p.stats + ((size_t)(r * 2 + which) * p.N + n0 + nl) * 2);
+          lo += w.lo; hi += w.hi;
+        }
+        t = det_value<KD6D_DET_ACT>(lo, hi);
+      }
       red[i] = t;
     }
     __syncthreads();
@@ -612,8 +662,9 @@ __device__ __forceinline__ void conv_epilogue_norm(const ConvParams& p, f32x4_t 
       if (g_first + gl < G) {
         int ks, hw;
         key_rows(key_lo + k, ks, hw);
-        const float* st = p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 2;
-        const float s1 = load_device_scope(st), s2 = load_device_scope(st + 1);
+        const long long* st = p.stats + ((size_t)(key_lo + k) * G + g_first + gl) * 4;
+        const det_words w1 = det_load_device_scope(st), w2 = det_load_device_scope(st + 2);
+        const float s1 = det_value<KD6D_DET_ACT>(w1.lo, w1.hi), s2 = det_value<KD6D_DET_ACT>(w2.lo, w2.hi);
         const float inv_n = 1.f / ((float)hw * (float)(1 << cs));
         mu = s1 * inv_n;
         rs = rsqrtf(fmaxf(s2 * inv_n - mu * mu, 0.f) + p.norm_eps);

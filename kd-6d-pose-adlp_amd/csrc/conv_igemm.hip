@@ -86,11 +86,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   if constexpr (XF) {
     const int R = p.xf_replicas > 1 ? p.xf_replicas : 1;
     for (int c = tid; c < p.C; c += 256) {
-      float s1 = 0.f, s2 = 0.f;
+      long long l1 = 0, h1 = 0, l2 = 0, h2 = 0;      // replica rows: the accumulators' words added as integers
       for (int r = 0; r < R; ++r) {
-        s1 += p.xf_sum[(size_t)(2 * r) * p.C + c];
-        s2 += p.xf_sum[(size_t)(2 * r + 1) * p.C + c];
+        const long long* a1 = p.xf_sum + ((size_t)(2 * r) * p.C + c) * 2;
+        const long long* a2 = p.xf_sum + ((size_t)(2 * r + 1) * p.C + c) * 2;
+        l1 += a1[0]; h1 += a1[1]; l2 += a2[0]; h2 += a2[1];
       }
+      const float s1 = det_value<KD6D_DET_ACT>(l1, h1), s2 = det_value<KD6D_DET_ACT>(l2, h2);
       const float mean = s1 * p.xf_inv_rows;
       const float var = fmaxf(s2 * p.xf_inv_rows - mean * mean, 0.f);
       const float is = rsqrtf(var + p.xf_eps);
@@ -632,7 +634,8 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_kernel(const ConvParams p,
 // Weight gradient:  dW[n][j] += sum_m dY[m][n] * im2col(X)[m][j],  j = (tap, ci).
 // Both operands are reduced along the pixel axis, which is the slow axis of NHWC,
 // so tiles are staged TRANSPOSED into the same 128-B-row LDS image (row = channel,
-// k = pixel) and consumed by the identical fragment reads.  fp32 atomics into dW.
+// k = pixel) and consumed by the identical fragment reads.  The partial tiles of the pixel splits meet in the
+// gradient bucket's PLANAR fixed-point accumulators (kd6d_det.h: integer atomics, bitwise reproducible).
 // ---------------------------------------------------------------------------
 struct WgradParams {
   int nseg, batch;
@@ -645,8 +648,9 @@ struct WgradParams {
   SegDev seg[kMaxSeg];
   const void* x;
   const void* dy;
-  float* dw;
-  float* dbias;   // optional: += column sums of dY (bias gradient), accumulated by the j-tile-0 workgroups
+  long long* dw;      // planar accumulators: word lo of element i at dw[i], word hi at dw[i + acc_hi]
+  long long* dbias;   // optional: += column sums of dY (bias gradient), accumulated by the j-tile-0 workgroups
+  long long acc_hi;
   int cu_budget;  // CUs this launch should aim to fill (callers that run several weight gradients side by side)
 };
 
@@ -831,19 +835,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 
-  // D rows = out channel n (4 per lane), D cols = j (lane&15)
+  // D rows = out channel n (4 per lane), D cols = j (lane&15): [n][j] fp32 image in LDS (the k-loop ended on a barrier),
+  // then one rolled loop of fixed-point adds (the conversion inlined at every accumulator multiplied the build time)
+  float* et = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
 #pragma unroll
     for (int b = 0; b < JI; ++b) {
-      const int j = j0 + wj * (BJ / WJ) + b * 16 + fr;
-      const int n = n0 + wn * (BN / WN) + a * 16 + fq * 4;
-      if (j >= p.J) continue;
+      const int jl = wj * (BJ / WJ) + b * 16 + fr;
+      const int nl = wn * (BN / WN) + a * 16 + fq * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (n + r < p.Cout) atomicAdd(p.dw + (size_t)(n + r) * (size_t)p.J + (size_t)j, acc[a][b][r]);
-      }
+      for (int r = 0; r < 4; ++r) et[(nl + r) * BJ + jl] = acc[a][b][r];
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < BN * BJ; i += 256) {
+    const int nl = i / BJ, jl = i - nl * BJ;
+    const int n = n0 + nl, j = j0 + jl;
+    if (n < p.Cout && j < p.J)
+      det_add_planar<KD6D_DET_GRAD>(p.dw + (size_t)n * (size_t)p.J + (size_t)j, p.acc_hi, et[i]);
   }
 }
 
@@ -856,8 +866,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // fragments (8 consecutive pixels of one channel per lane) come out of ds_read_b64_tr_b16, the
 // gfx950 transposing LDS read: conflict-free for the two 4-row blocks a 32-lane half fetches.
 // Split over pixel ranges; partial tiles are re-laid out through LDS so every atomic wave-instruction
-// adds 256 contiguous bytes of one dW row.  The split count balances the k-loop against the
-// ~1.3 TB/s fp32-atomic rate of the memory side (launch_wgrad_tr).
+// adds 64 consecutive elements of one dW row (512 contiguous bytes of the accumulators' lo plane).  The split count
+// balances the k-loop against the atomic rate of the memory side (launch_wgrad_tr).
 // ---------------------------------------------------------------------------
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
@@ -1029,8 +1039,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
     // block-level reduction in LDS (the staging buffers are dead: the k-loop ended on a barrier), then
     // ONE atomic wave-instruction per 64 channels: the memory side retires ~one atomic instruction
     // per 50 ns per CU however few lanes it carries
-    float* bred = reinterpret_cast<float*>(smem);
-    for (int i = tid; i < BN; i += 256) bred[i] = 0.f;
+    long long* bred = reinterpret_cast<long long*>(smem);     // BN accumulators {lo, hi}
+    for (int i = tid; i < 2 * BN; i += 256) bred[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LN; ++i)
@@ -1039,14 +1049,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
         float v = bacc[i][e];
 #pragma unroll
         for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);   // lanes with equal lane&3: same channels
-        if (lane < 4 && sub + 4 * i < GN) atomicAdd(&bred[(sub + 4 * i) * 8 + e], v);
+        if (lane < 4 && sub + 4 * i < GN) det_add_lds<KD6D_DET_GRAD>(&bred[((sub + 4 * i) * 8 + e) * 2], v);
       }
     __syncthreads();
     for (int i = tid; i < BN; i += 256)
-      if (n0 + i < p.Cout) atomicAdd(p.dbias + n0 + i, bred[i]);
+      if (n0 + i < p.Cout) det_add_words_planar(p.dbias + n0 + i, p.acc_hi, bred[2 * i], bred[2 * i + 1]);
     __syncthreads();
   }
-  // ---- epilogue: [n][j] fp32 image in LDS, then 256-B contiguous atomic rows ----
+  // ---- epilogue: [n][j] fp32 image in LDS, then rows of 64 consecutive accumulators per wave instruction ----
   float* et = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int a = 0; a < NI; ++a)
@@ -1065,7 +1075,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
     for (int h = 0; h < BJ / 64; ++h) {
       const int jl = h * 64 + lane;
       const int j = j0 + jl;
-      if (j < p.J) atomicAdd(p.dw + (size_t)n * (size_t)p.J + (size_t)j, et[nl * EP + jl]);
+      if (j < p.J) det_add_planar<KD6D_DET_GRAD>(p.dw + (size_t)n * (size_t)p.J + (size_t)j, p.acc_hi, et[nl * EP + jl]);
     }
   }
 }
@@ -1182,18 +1192,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradParams
     }
     cur ^= 1;
   }
-  // ---- one flush per workgroup ----
+  // ---- one flush per workgroup: [n][j] fp32 image in LDS (launch_wgrad_small sizes it), one rolled loop of adds ----
+  constexpr int JP = JB * 16;
+  __syncthreads();                       // the last tile's fragment reads are done
+  float* et = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int blk = wave + 4 * i;
     if (blk >= NBLK) continue;
     const int nb = blk / JB, jb = blk - nb * JB;
-    const int j = jb * 16 + fr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nb * 16 + fq * 4 + r;
-      if (n < p.Cout && j < J) atomicAdd(p.dw + (size_t)n * J + j, acc[i][r]);
-    }
+    for (int r = 0; r < 4; ++r) et[(nb * 16 + fq * 4 + r) * JP + jb * 16 + fr] = acc[i][r];
+  }
+  __syncthreads();
+  for (int i = tid; i < NB * 16 * JP; i += 256) {
+    const int n = i / JP, j = i - n * JP;
+    if (n < p.Cout && j < J) det_add_planar<KD6D_DET_GRAD>(p.dw + (size_t)n * J + j, p.acc_hi, et[i]);
   }
 }
 
@@ -1487,7 +1501,9 @@ void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
   const int ntiles = (p.Cout + BN - 1) / BN;
   const int tiles = q.n_jtiles * ntiles;
   const int steps_total = (p.M + BKM - 1) / BKM;
-  // time ~ (steps/S) * t_step + S * |dW| / (fp32 atomic rate 1.3 TB/s), t_step ~ 1.6 us measured
+  // time ~ (steps/S) * t_step + S * |dW| / (atomic rate: 1.3 TB/s measured for fp32 adds in rounds 1-3; the 64-bit
+  // integer adds of the reproducible accumulators move twice the bytes per element at 0.6-0.75x the element rate,
+  // tools/microbench/atomic_rate.hip), t_step ~ 1.6 us measured
   //   => S* = sqrt(steps * t_step * rate / |dW|); at most 2 workgroups per CU, because many
   //   workgroups adding into one small dW are contention-bound (measured: 2048 -> 512 = -25 %)
   // a caller that keeps several weight gradients in flight asks each for a fraction of the device: fewer,
@@ -1527,7 +1543,9 @@ void launch_wgrad_small(const WgradParams& p, int R, hipStream_t st) {
   const int ntiles = p.batch * tiles_per_img;
   int grid = 2 * p.cu_budget;                                  // persistent: one flush per workgroup
   if (grid > ntiles) grid = ntiles;
-  const size_t lds = (size_t)2 * buf_bytes;
+  constexpr int JB_ = (KS * KS * 8 * CG + 15) / 16;
+  const size_t image = (size_t)NB * 16 * JB_ * 16 * sizeof(float);      // the flush's [n][j] image
+  const size_t lds = (size_t)2 * buf_bytes > image ? (size_t)2 * buf_bytes : image;
   auto kern = conv_wgrad_small_kernel<CG, NB, KS>;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
@@ -1624,13 +1642,13 @@ int fwd_params(const kd6d_conv_geom* g, int dtype, const char* who, ConvParams& 
   return KD6D_OK;
 }
 
-int set_stats(const kd6d_conv_geom* g, ConvParams& p, float* stats, int stats_groups, const char* who) {
+int set_stats(const kd6d_conv_geom* g, ConvParams& p, kd6d_acc* stats, int stats_groups, const char* who) {
   KD6D_CHECK_ARG(g->cout % 4 == 0 && stats_groups >= 0, "%s: fused statistics need cout %% 4 == 0", who);
   KD6D_CHECK_ARG(stats_groups == 0 || (g->cout % stats_groups == 0 && (g->cout / stats_groups) % 4 == 0 &&
                                        g->cout / stats_groups <= 8),
                  "%s: fused group statistics need 4 or 8 channels per group (cout=%d, groups=%d)", who, g->cout,
                  stats_groups);
-  p.stats = stats; p.stats_groups = stats_groups;
+  p.stats = reinterpret_cast<long long*>(stats); p.stats_groups = stats_groups;
   if (stats_groups > 0) p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
   return KD6D_OK;
 }
@@ -1642,7 +1660,8 @@ bool norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups, Conv
   if (((int)kd6d_opt(KD6D_OPT_CONV_FUSE_NORM) & (kind == KD6D_NORM_GROUP ? 1 : 2)) == 0) return false;
   if (fwd_params(g, dtype, "kd6d_conv2d_fwd_norm", p) != KD6D_OK) return false;
   static float dummy;
-  if (set_stats(g, p, &dummy, kind == KD6D_NORM_GROUP ? groups : 0, "kd6d_conv2d_fwd_norm") != KD6D_OK) return false;
+  static kd6d_acc dummy_acc;
+  if (set_stats(g, p, &dummy_acc, kind == KD6D_NORM_GROUP ? groups : 0, "kd6d_conv2d_fwd_norm") != KD6D_OK) return false;
   if (kind == KD6D_NORM_GROUP && groups <= 0) return false;
   p.norm_dst = &dummy;
   p.out_f32 = 1;
@@ -1676,7 +1695,7 @@ bool norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups, Conv
 extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x, const void* w,
                                void* y, const float* ch_scale, const float* ch_shift, int act,
                                const void* residual, const float* seg_scale, int out_f32,
-                               float* stats, int stats_groups, void* workspace, int64_t workspace_bytes,
+                               kd6d_acc* stats, int stats_groups, void* workspace, int64_t workspace_bytes,
                                void* stream) {
   ConvParams p;
   int rc = fwd_params(g, dtype, "kd6d_conv2d_fwd", p);
@@ -1696,7 +1715,7 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
 }
 
 extern "C" int kd6d_conv2d_fwd_block(const kd6d_conv_geom* g, int dtype, const void* x, const kd6d_bn_in* bn, void* z_out,
-                                     const void* w, float* y_raw, float* stats, int stats_replicas, void* stream) {
+                                     const void* w, float* y_raw, kd6d_acc* stats, int stats_replicas, void* stream) {
   ConvParams p;
   int rc = fwd_params(g, dtype, "kd6d_conv2d_fwd_block", p);
   if (rc) return rc;
@@ -1720,7 +1739,7 @@ extern "C" int kd6d_conv2d_fwd_block(const kd6d_conv_geom* g, int dtype, const v
                    "kd6d_conv2d_fwd_block: BatchNorm-on-load needs a 1x1 or 3x3 stride-1 'same' convolution");
     long long rows_in = 0;
     for (int s = 0; s < g->nseg; ++s) rows_in += (long long)g->batch * g->seg[s].in_h * g->seg[s].in_w;
-    p.xf_sum = bn->sums; p.xf_replicas = bn->replicas; p.xf_gamma = bn->gamma; p.xf_beta = bn->beta;
+    p.xf_sum = reinterpret_cast<const long long*>(bn->sums); p.xf_replicas = bn->replicas; p.xf_gamma = bn->gamma; p.xf_beta = bn->beta;
     p.xf_eps = bn->eps; p.xf_momentum = bn->momentum; p.xf_act = bn->act;
     p.xf_inv_rows = 1.0f / (float)rows_in;
     p.xf_unbias = rows_in > 1 ? (float)rows_in / (float)(rows_in - 1) : 1.0f;
@@ -1759,7 +1778,7 @@ extern "C" int kd6d_conv2d_fwd_norm(const kd6d_conv_geom* g, int dtype, const vo
   KD6D_CHECK_ARG(timeouts != nullptr, "kd6d_conv2d_fwd_norm: no barrier-timeout counter");
   p.src = x; p.wgt = w; p.dst = raw_out;
   p.ch_shift = bias; p.act = KD6D_ACT_NONE; p.out_f32 = 1;
-  p.stats = norm->stats;
+  p.stats = reinterpret_cast<long long*>(norm->stats);
   p.norm_dst = norm->y; p.norm_gamma = norm->gamma; p.norm_beta = norm->beta;
   p.norm_ctr = norm->counters; p.norm_timeouts = timeouts;
   p.norm_eps = norm->eps; p.norm_act = norm->act;
@@ -1805,13 +1824,17 @@ extern "C" int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void*
   return KD6D_OK;
 }
 
-extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum, float* sumsq, void* stream);
+// norm_ops.hip: per-channel column sums of a (rows, C) tensor into PLANAR gradient accumulators
+namespace kd6d_detail {
+int colsum_grad_planar(int dtype, const void* x, int64_t rows, int C, long long* acc, long long acc_hi, void* stream);
+}
 
 extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy,
-                                 float* dw, float* dbias, int cu_budget, void* stream) {
+                                 int64_t* dw, int64_t* dbias, int64_t acc_hi_stride, int cu_budget, void* stream) {
   int rc = check_geom(g, dtype, "kd6d_conv2d_wgrad");
   if (rc) return rc;
   KD6D_CHECK_ARG(x && dy && dw, "kd6d_conv2d_wgrad: null tensor pointer");
+  KD6D_CHECK_ARG(acc_hi_stride != 0, "kd6d_conv2d_wgrad: acc_hi_stride = 0 (planar accumulators: lo plane, hi plane)");
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   KD6D_CHECK_ARG(g->cout % eg == 0, "kd6d_conv2d_wgrad: cout=%d must be a multiple of %d", g->cout, eg);
   WgradParams p;
@@ -1823,7 +1846,8 @@ extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void*
   for (int s = 0; s < g->nseg; ++s)
     KD6D_CHECK_ARG(p.seg[s].dst_row0 == p.seg[s].m_begin,
                    "kd6d_conv2d_wgrad: output levels must be packed back to back");
-  p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias;
+  p.x = x; p.dy = dy;
+  p.dw = reinterpret_cast<long long*>(dw); p.dbias = reinterpret_cast<long long*>(dbias); p.acc_hi = (long long)acc_hi_stride;
   const int ncu = cached_cu_count();
   KD6D_CHECK_ARG(cu_budget >= 0, "kd6d_conv2d_wgrad: cu_budget=%d", cu_budget);
   p.cu_budget = (cu_budget == 0 || cu_budget > ncu) ? ncu : cu_budget;
@@ -1833,7 +1857,7 @@ extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void*
   } else {
     dispatch_wgrad<float>(p, st);
     if (dbias) {           // exact-fp32 parity path: separate column-sum pass
-      rc = kd6d_colstats(dtype, dy, p.M, g->cout, dbias, nullptr, stream);
+      rc = kd6d_detail::colsum_grad_planar(dtype, dy, p.M, g->cout, p.dbias, p.acc_hi, stream);
       if (rc) return rc;
     }
   }

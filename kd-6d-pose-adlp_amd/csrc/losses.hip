@@ -12,6 +12,7 @@
 // Logit layout: cls (rows,16) fp32 [15 classes + 1 pad], reg (rows,240) fp32, rows packed
 // level-major / image / row-major (the conv kernels' packed NHWC order).
 #include "kd6d_common.h"
+#include "kd6d_det.h"
 
 namespace {
 
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kT) void ssc_assign_kernel(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void focal_fwd_kernel(const float* __restrict__ cls,
                                                        const int* __restrict__ labels, int rows,
-                                                       float gamma, float alpha, float* loss) {
+                                                       float gamma, float alpha, float* loss, long long* loss_ws) {
   __shared__ float s_part[kT / 64];
   float acc = 0.f;
   const long long total = (long long)rows * 15;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kT) void focal_fwd_kernel(const float* __restrict__
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int w = 0; w < kT / 64; ++w) s += s_part[w];
-    atomicAdd(loss, s);
+    kd6d_detail::det_scalar_arrive<KD6D_DET_ACT>(loss_ws, s, gridDim.x, loss);
   }
 }
 
@@ -500,7 +501,7 @@ struct StudentArgs {
   float kinv[9];
   float frame_w, frame_h;
   int cap;
-  float* xs; float* alpha; float* g_reg_xy; float* loss_reg; int* s_start;
+  float* xs; float* alpha; float* g_reg_xy; float* loss_reg; long long* loss_reg_ws; int* s_start;
 };
 
 __device__ __forceinline__ void locate_row(const Levels& L, int row, int& l, int& cell, int& w,
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(kT) void student_points_kernel(Levels L, StudentArg
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int w = 0; w < kT / 64; ++w) s += s_part[w];
-    atomicAdd(a.loss_reg, s);
+    kd6d_detail::det_scalar_arrive<KD6D_DET_ACT>(a.loss_reg_ws, s, gridDim.x, a.loss_reg);
   }
 }
 
@@ -598,7 +599,8 @@ struct BackwardArgs {
   const int* n_valid; const int* valid_img;
   const float* weights;      // {w_cls, w_reg, w_kd} upstream gradients of the three losses
   const float* seg_scale;    // PoseHead.scales (per level), may be null
-  float* dseg_scale;         // gradient of the scales (fp32, accumulated), may be null
+  long long* dseg_scale;     // gradient of the scales: planar accumulators of the gradient bucket (kd6d.h), may be null
+  long long acc_hi;
   float frame_w, frame_h;
   int cap; int detach_alpha;
   void* dcls; void* dreg;
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(kT) void loss_backward_kernel(Levels L, BackwardArg
       if (a.dseg_scale) {
         const float* r = a.reg + (size_t)row * 240 + c * 16;
         // d/dscale = sum grad * raw = sum grad * out / scale
-        atomicAdd(a.dseg_scale + l, (dpx * r[k] + dpy * r[8 + k]) / sc);
+        kd6d_detail::det_add_planar<KD6D_DET_GRAD>(a.dseg_scale + l, a.acc_hi, (dpx * r[k] + dpy * r[8 + k]) / sc);
       }
     }
     dreg[(size_t)row * 240 + c * 16 + k] = from_f32<T>(dpx * sc);
@@ -746,12 +748,12 @@ extern "C" int kd6d_ssc_assign(const kd6d_levels* levels, const float* mask, int
 }
 
 extern "C" int kd6d_focal_fwd(const float* cls, const int32_t* labels, int rows, float gamma, float alpha,
-                              float* loss, void* stream) {
-  KD6D_CHECK_ARG(cls && labels && loss && rows > 0, "kd6d_focal_fwd: bad arguments");
+                              float* loss, kd6d_scalar_ws* loss_ws, void* stream) {
+  KD6D_CHECK_ARG(cls && labels && loss && loss_ws && rows > 0, "kd6d_focal_fwd: bad arguments");
   int nb = (rows * 15 + kT - 1) / kT;
   if (nb > 128) nb = 128;        // one same-address atomic per workgroup, retired serially: 1024 of them were the kernel
   hipLaunchKernelGGL(focal_fwd_kernel, dim3(nb), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), cls, labels,
-                     rows, gamma, alpha, loss);
+                     rows, gamma, alpha, loss, reinterpret_cast<long long*>(loss_ws));
   KD6D_CHECK_LAUNCH("kd6d_focal_fwd");
   return KD6D_OK;
 }
@@ -778,12 +780,12 @@ extern "C" int kd6d_student_points(const kd6d_levels* levels, const float* cls, 
                                    const int32_t* class_ids, const float* kp3d, const float* rot,
                                    const float* trans, const float* bbox_trans, const float* diameters,
                                    const float* kinv_host, float frame_w, float frame_h, int cap, float* xs,
-                                   float* alpha, float* g_reg_xy, float* loss_reg, int32_t* s_start,
-                                   void* stream) {
+                                   float* alpha, float* g_reg_xy, float* loss_reg, kd6d_scalar_ws* loss_reg_ws,
+                                   int32_t* s_start, void* stream) {
   Levels L;
   KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_student_points: bad level table");
   KD6D_CHECK_ARG(cls && reg && pos_cnt && pos_row && pos_gt && class_ids && kp3d && rot && trans &&
-                     bbox_trans && diameters && kinv_host && xs && alpha && g_reg_xy && loss_reg && s_start,
+                     bbox_trans && diameters && kinv_host && xs && alpha && g_reg_xy && loss_reg && loss_reg_ws && s_start,
                  "kd6d_student_points: null pointer");
   StudentArgs a;
   a.cls = cls; a.reg = reg; a.pos_cnt = pos_cnt; a.pos_row = pos_row; a.pos_gt = pos_gt;
@@ -791,7 +793,7 @@ extern "C" int kd6d_student_points(const kd6d_levels* levels, const float* cls, 
   a.diameters = diameters;
   for (int i = 0; i < 9; ++i) a.kinv[i] = kinv_host[i];
   a.frame_w = frame_w; a.frame_h = frame_h; a.cap = cap;
-  a.xs = xs; a.alpha = alpha; a.g_reg_xy = g_reg_xy; a.loss_reg = loss_reg; a.s_start = s_start;
+  a.xs = xs; a.alpha = alpha; a.g_reg_xy = g_reg_xy; a.loss_reg = loss_reg; a.loss_reg_ws = reinterpret_cast<long long*>(loss_reg_ws); a.s_start = s_start;
   hipLaunchKernelGGL(student_points_kernel, dim3(L.batch), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), L, a);
   KD6D_CHECK_LAUNCH("kd6d_student_points");
   return KD6D_OK;
@@ -811,8 +813,8 @@ extern "C" int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const fl
                                   const int32_t* class_ids, const float* bbox_trans, const float* g_reg_xy,
                                   const float* g_kd_xs, const float* g_kd_alpha, const int32_t* n_valid,
                                   const int32_t* valid_img, const float* weights, const float* seg_scale,
-                                  float* dseg_scale, float frame_w, float frame_h, int cap, int detach_alpha,
-                                  void* dcls, void* dreg, void* stream) {
+                                  int64_t* dseg_scale_acc, int64_t acc_hi_stride, float frame_w, float frame_h, int cap,
+                                  int detach_alpha, void* dcls, void* dreg, void* stream) {
   Levels L;
   KD6D_CHECK_ARG(fill_levels(levels, &L), "kd6d_loss_backward: bad level table");
   KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_loss_backward: bad dtype");
@@ -823,7 +825,8 @@ extern "C" int kd6d_loss_backward(const kd6d_levels* levels, int dtype, const fl
   a.cls = cls; a.reg = reg; a.pos_cnt = pos_cnt; a.pos_row = pos_row; a.pos_gt = pos_gt; a.class_ids = class_ids;
   a.bbox_trans = bbox_trans; a.g_reg_xy = g_reg_xy; a.g_kd_xs = g_kd_xs; a.g_kd_alpha = g_kd_alpha;
   a.n_valid = n_valid; a.valid_img = valid_img; a.weights = weights; a.seg_scale = seg_scale;
-  a.dseg_scale = dseg_scale; a.frame_w = frame_w; a.frame_h = frame_h; a.cap = cap;
+  KD6D_CHECK_ARG(!dseg_scale_acc || acc_hi_stride != 0, "kd6d_loss_backward: acc_hi_stride = 0 with gradient accumulators");
+  a.dseg_scale = reinterpret_cast<long long*>(dseg_scale_acc); a.acc_hi = (long long)acc_hi_stride; a.frame_w = frame_w; a.frame_h = frame_h; a.cap = cap;
   a.detach_alpha = detach_alpha; a.dcls = dcls; a.dreg = dreg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == KD6D_BF16) hipLaunchKernelGGL(loss_backward_kernel<bf16_t>, dim3(L.batch), dim3(kT), 0, st, L, a);

@@ -6,14 +6,25 @@
 //   MaxPool2d(2,2), backbone/darknet.py:94-97
 //   F.interpolate(nearest, x2) + add of the FPN top-down path, models/model.py:75-78
 //   F.relu between P6 and P7, models/model.py:101
-// All reductions accumulate in fp32; every kernel reads/writes 16-B granules.
+// Every kernel reads/writes 16-B granules.  Reductions: fp32 inside a thread (fixed order), then -- across the threads
+// of a workgroup and across workgroups -- 64-bit integer atomics on fixed-point accumulators (kd6d_det.h), so every
+// statistic and every gradient sum is BITWISE reproducible from run to run whatever order the atomics retire in.
 #include "kd6d_barrier.h"
 #include "kd6d_common.h"
+#include "kd6d_det.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-using kd6d_detail::atomic_add_performed;
+using kd6d_detail::det_add_lds;
+using kd6d_detail::det_add_words;
+using kd6d_detail::det_add_words_performed;
+using kd6d_detail::det_add_words_planar;
+using kd6d_detail::det_load_device_scope;
+using kd6d_detail::det_read;
+using kd6d_detail::det_value;
+using kd6d_detail::det_words;
+typedef long long acc_t;            // one word of an accumulator {lo, hi} (kd6d_acc = two of them)
 
 // ---------------------------------------------------------------------------
 // Per-channel reductions over rows.  Thread t owns channel granule t % (C/EG);
@@ -25,17 +36,18 @@ __device__ __forceinline__ float row_ror_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + O, 0xF, 0xF, true));
 }
 
-// out[a]: `replicas` rows of C floats; this workgroup adds into row blockIdx.x % replicas (the rows are summed
-// by the consumer), so an address sees 1/replicas of the serially retired atomics.
-template <int NACC, int EG, bool PERFORMED = false>
+// out[a]: `replicas` rows of C accumulators; this workgroup adds into row blockIdx.x % replicas (the rows are summed
+// by the consumer), so an address sees 1/replicas of the serially retired atomics.  E: KD6D_DET_ACT / KD6D_DET_GRAD.
+// Dynamic LDS: NACC * C accumulators (16 bytes each).
+// PLANAR: out[a] is the lo plane of a gradient-bucket accumulator array (hi words at + hi_off, no replica rows).
+template <int NACC, int EG, int E, bool PERFORMED = false, bool PLANAR = false>
 __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int C, int cg,
-                                                    float* const* out, int replicas = 1) {
-  extern __shared__ float red[];  // NACC * C floats
-  for (int i = threadIdx.x; i < NACC * C; i += kThreads) red[i] = 0.f;
+                                                    acc_t* const* out, int replicas = 1, long long hi_off = 0) {
+  extern __shared__ acc_t lds_acc[];  // NACC * C * {lo, hi}
+  for (int i = threadIdx.x; i < NACC * C * 2; i += kThreads) lds_acc[i] = 0;
   __syncthreads();
   // narrow tensors (C/EG < 16): the lanes of a 16-lane row that own the same channel granule are summed
-  // with DPP rotations first, so an LDS address sees 16 adds per workgroup instead of up to 256
-  // (same-address LDS float atomics serialise)
+  // with DPP rotations first (a fixed order), so an LDS address sees 16 adds per workgroup instead of up to 256
   const int cgs = C / EG;
   const bool pre = cgs < 16 && (16 % cgs) == 0;
   if (pre) {
@@ -55,20 +67,25 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int e = 0; e < EG; ++e) atomicAdd(&red[a * C + cg * EG + e], acc[a][e]);
+      for (int e = 0; e < EG; ++e) det_add_lds<E>(&lds_acc[(a * C + cg * EG + e) * 2], acc[a][e]);
   }
   __syncthreads();
   const int roff = replicas > 1 ? (int)(blockIdx.x % replicas) * C : 0;
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
     const int a = i / C, c = i - a * C;
     if (out[a]) {
-      if (PERFORMED) atomic_add_performed(out[a] + roff + c, red[i]);
-      else atomicAdd(out[a] + roff + c, red[i]);
+      if (PLANAR) {
+        det_add_words_planar(out[a] + c, hi_off, lds_acc[2 * i], lds_acc[2 * i + 1]);
+      } else {
+        acc_t* o = out[a] + (size_t)(roff + c) * 2;
+        if (PERFORMED) det_add_words_performed(o, lds_acc[2 * i], lds_acc[2 * i + 1]);
+        else det_add_words(o, lds_acc[2 * i], lds_acc[2 * i + 1]);
+      }
     }
   }
 }
 
-// In-kernel barriers: kd6d_barrier.h (atomic_add_performed, group_barrier, grid_barrier, the residency argument).  The
+// In-kernel barriers: kd6d_barrier.h (returning atomics, group_barrier, grid_barrier, the residency argument).  The
 // kernels of this file count their give-ups here; the convolution epilogues add to the same word through its device
 // address (barrier_timeouts_device_ptr).
 __device__ unsigned int g_barrier_timeouts = 0;      // the default context's counter; other contexts own a word each
@@ -81,9 +98,10 @@ __device__ __forceinline__ void grid_barrier(unsigned int* ctr, unsigned nblocks
 
 // Row-tiled variant of the ownership rule: thread t owns channel granule t % cgs of row t / cgs
 // (threads beyond (256/cgs)*cgs idle), so any C with C/EG <= 256 works (e.g. C = 240 bias grads).
-template <typename T>
+// GRAD: the column sums are a bias gradient -- class KD6D_DET_GRAD, planar accumulators (hi words at + hi_off)
+template <typename T, bool GRAD = false>
 __global__ __launch_bounds__(kThreads) void colstats_kernel(const T* __restrict__ x, long long rows,
-                                                            int C, float* sum, float* sumsq) {
+                                                            int C, acc_t* sum, acc_t* sumsq, long long hi_off) {
   constexpr int EG = Granule<T>::N;
   const int cgs = C / EG;
   const int rpp = kThreads / cgs;            // rows per pass
@@ -102,8 +120,9 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const T* __restrict_
       for (int e = 0; e < EG; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
     }
   }
-  float* outs[2] = {sum, sumsq};
-  block_channel_flush<2, EG>(acc, C, cg, outs);
+  acc_t* outs[2] = {sum, sumsq};
+  if (GRAD) block_channel_flush<2, EG, KD6D_DET_GRAD, false, true>(acc, C, cg, outs, 1, hi_off);
+  else block_channel_flush<2, EG, KD6D_DET_ACT>(acc, C, cg, outs);
 }
 
 // Granule g (EG consecutive channels) of a tensor stored as TX; TX = float with EG = 8 is the
@@ -142,7 +161,7 @@ __device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float g
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     const TX* __restrict__ x, T* __restrict__ y, long long ngran, int C, float inv_rows,
-    const float* __restrict__ sum, const float* __restrict__ sumsq, const float* __restrict__ gamma,
+    const acc_t* __restrict__ sum, const acc_t* __restrict__ sumsq, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float unbias,
     float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act) {
   constexpr int EG = Granule<T>::N;
@@ -152,16 +171,16 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
-    const float m = sum[c] * inv_rows;
-    float var = sumsq[c] * inv_rows - m * m;
+    const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
+    float var = det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m;
     var = fmaxf(var, 0.f);
     const float is = rsqrtf(var + eps);
     bn_scale_shift(m, is, gamma[c], beta[c], sc[e], sh[e]);
   }
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += kThreads) {
-      const float m = sum[c] * inv_rows;
-      float var = fmaxf(sumsq[c] * inv_rows - m * m, 0.f);
+      const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
+      float var = fmaxf(det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m, 0.f);
       if (save_mean) save_mean[c] = m;
       if (save_invstd) save_invstd[c] = rsqrtf(var + eps);
       if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
@@ -185,8 +204,8 @@ template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, long long ngran, int C,
     const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy,
-    float* sum_dy_xhat, int replicas) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, acc_t* sum_dy,
+    acc_t* sum_dy_xhat, int replicas) {
   constexpr int EG = Granule<T>::N;
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
@@ -217,8 +236,19 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
       acc[1][e] += d * xh;
     }
   }
-  float* outs[2] = {sum_dy, sum_dy_xhat};
-  block_channel_flush<2, EG>(acc, C, cg, outs, replicas);
+  acc_t* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG, KD6D_DET_GRAD>(acc, C, cg, outs, replicas);
+}
+
+// total of `replicas` rows of C accumulators at channel c: the words are added as integers (exact), converted once
+template <int E>
+__device__ __forceinline__ float replica_sum(const acc_t* __restrict__ rows, int C, int replicas, int c) {
+  acc_t lo = 0, hi = 0;
+  for (int r = 0; r < replicas; ++r) {
+    lo += rows[((size_t)r * C + c) * 2];
+    hi += rows[((size_t)r * C + c) * 2 + 1];
+  }
+  return det_value<E>(lo, hi);
 }
 
 template <typename T, typename TX>
@@ -226,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int C,
     float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* dgamma,
+    const acc_t* __restrict__ sum_dy, const acc_t* __restrict__ sum_dy_xhat, float* dgamma,
     float* dbeta, int replicas) {
   constexpr int EG = Granule<T>::N;
   extern __shared__ float tot[];             // 2 * C: replica rows of the two reductions, summed once per workgroup
@@ -238,38 +268,19 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     const int c = cg * EG + e;
     m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
   }
-  if (replicas > 1) {                        // wave-uniform
-    for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
-      const float* __restrict__ src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
-      float t = src[0];
-      for (int r = 1; r < replicas; ++r) t += src[(size_t)r * C];
-      tot[i] = t;
-    }
-    __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads)
+    tot[i] = i < C ? replica_sum<KD6D_DET_GRAD>(sum_dy, C, replicas, i) : replica_sum<KD6D_DET_GRAD>(sum_dy_xhat, C, replicas, i - C);
+  __syncthreads();
 #pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      const int c = cg * EG + e;
-      k1[e] = tot[c] * inv_rows;
-      k2[e] = tot[C + c] * inv_rows;
-    }
-    if (blockIdx.x == 0) {
-      for (int c = threadIdx.x; c < C; c += kThreads) {
-        if (dgamma) dgamma[c] += tot[C + c];
-        if (dbeta) dbeta[c] += tot[c];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      const int c = cg * EG + e;
-      k1[e] = sum_dy[c] * inv_rows;
-      k2[e] = sum_dy_xhat[c] * inv_rows;
-    }
-    if (blockIdx.x == 0) {
-      for (int c = threadIdx.x; c < C; c += kThreads) {
-        if (dgamma) dgamma[c] += sum_dy_xhat[c];
-        if (dbeta) dbeta[c] += sum_dy[c];
-      }
+  for (int e = 0; e < EG; ++e) {
+    const int c = cg * EG + e;
+    k1[e] = tot[c] * inv_rows;
+    k2[e] = tot[C + c] * inv_rows;
+  }
+  if (blockIdx.x == 0) {                     // one writer per channel: plain adds, reproducible
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+      if (dgamma) dgamma[c] += tot[C + c];
+      if (dbeta) dbeta[c] += tot[c];
     }
   }
   const u32x4_t* dg = reinterpret_cast<const u32x4_t*>(dz);
@@ -335,7 +346,7 @@ __device__ __forceinline__ long long pool_tap(const PoolWin& w, int k) {
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_pool_fwd_kernel(
     const TX* __restrict__ x, T* __restrict__ y, int items, int H, int W, int C, float inv_rows,
-    const float* __restrict__ sum, const float* __restrict__ sumsq, const float* __restrict__ gamma,
+    const acc_t* __restrict__ sum, const acc_t* __restrict__ sumsq, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float unbias,
     float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act) {
   constexpr int EG = Granule<T>::N;
@@ -345,15 +356,15 @@ __global__ __launch_bounds__(kThreads) void bn_pool_fwd_kernel(
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
-    const float m = sum[c] * inv_rows;
-    float var = sumsq[c] * inv_rows - m * m;
+    const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
+    float var = det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m;
     var = fmaxf(var, 0.f);
     bn_scale_shift(m, rsqrtf(var + eps), gamma[c], beta[c], sc[e], sh[e]);
   }
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += kThreads) {
-      const float m = sum[c] * inv_rows;
-      float var = fmaxf(sumsq[c] * inv_rows - m * m, 0.f);
+      const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
+      float var = fmaxf(det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m, 0.f);
       if (save_mean) save_mean[c] = m;
       if (save_invstd) save_invstd[c] = rsqrtf(var + eps);
       if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
@@ -405,7 +416,7 @@ template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_pool_bwd_reduce_kernel(
     const TX* __restrict__ x, const T* __restrict__ dy, int items, int H, int W, int C,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat, int replicas) {
+    const float* __restrict__ beta, int act, acc_t* sum_dy, acc_t* sum_dy_xhat, int replicas) {
   constexpr int EG = Granule<T>::N;
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
@@ -437,8 +448,8 @@ __global__ __launch_bounds__(kThreads) void bn_pool_bwd_reduce_kernel(
       acc[1][e] += d * xa;
     }
   }
-  float* outs[2] = {sum_dy, sum_dy_xhat};
-  block_channel_flush<2, EG>(acc, C, cg, outs, replicas);
+  acc_t* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG, KD6D_DET_GRAD>(acc, C, cg, outs, replicas);
 }
 
 template <typename T, typename TX>
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void bn_pool_bwd_apply_kernel(
     const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int items, int H, int W, int C,
     float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* dgamma, float* dbeta,
+    const acc_t* __restrict__ sum_dy, const acc_t* __restrict__ sum_dy_xhat, float* dgamma, float* dbeta,
     int replicas) {
   constexpr int EG = Granule<T>::N;
   extern __shared__ float tot[];             // 2 * C
@@ -459,12 +470,8 @@ __global__ __launch_bounds__(kThreads) void bn_pool_bwd_apply_kernel(
     m[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
     bn_scale_shift(m[e], is[e], ga[e], be[e], sc[e], sh[e]);
   }
-  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
-    const float* __restrict__ src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
-    float t = src[0];
-    for (int r = 1; r < replicas; ++r) t += src[(size_t)r * C];
-    tot[i] = t;
-  }
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads)
+    tot[i] = i < C ? replica_sum<KD6D_DET_GRAD>(sum_dy, C, replicas, i) : replica_sum<KD6D_DET_GRAD>(sum_dy_xhat, C, replicas, i - C);
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < EG; ++e) {
@@ -514,21 +521,24 @@ __global__ __launch_bounds__(kThreads) void bn_pool_bwd_apply_kernel(
 constexpr int kBnHold = 4;
 constexpr int kBnOnepassBlocks = 512;
 
-// totals of the replica rows -> tot[2C] (LDS), read with device-scope atomic loads (see group_barrier)
-__device__ __forceinline__ void replica_totals(const float* sum_dy, const float* sum_dy_xhat, int C, int replicas,
+// totals of the replica rows -> tot[2C] (LDS floats), read with device-scope atomic loads (see group_barrier); the
+// words of the rows are added as integers (exact) and converted once
+__device__ __forceinline__ void replica_totals(const acc_t* sum_dy, const acc_t* sum_dy_xhat, int C, int replicas,
                                                float* tot) {
   for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
-    const float* src = i < C ? sum_dy + i : sum_dy_xhat + (i - C);
-    float t = 0.f;
-    for (int r0 = 0; r0 < replicas; r0 += 8) {           // eight loads in flight: one memory round trip, not eight
-      float v[8];
+    const acc_t* src = i < C ? sum_dy + 2 * i : sum_dy_xhat + 2 * (i - C);
+    acc_t lo = 0, hi = 0;
+    for (int r0 = 0; r0 < replicas; r0 += 8) {           // eight rows in flight: one memory round trip, not eight
+      det_words v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        v[r] = r0 + r < replicas ? __hip_atomic_load(src + (size_t)(r0 + r) * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      for (int r = 0; r < 8; ++r) {
+        v[r].lo = 0; v[r].hi = 0;
+        if (r0 + r < replicas) v[r] = det_load_device_scope(src + (size_t)(r0 + r) * C * 2);
+      }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) t += v[r];
+      for (int r = 0; r < 8; ++r) { lo += v[r].lo; hi += v[r].hi; }
     }
-    tot[i] = t;
+    tot[i] = det_value<KD6D_DET_GRAD>(lo, hi);
   }
   __syncthreads();
 }
@@ -537,10 +547,11 @@ template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads, 3) void bn_bwd_onepass_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, long long ngran, int per_thread, int C,
     float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, acc_t* sum_dy, acc_t* sum_dy_xhat,
     unsigned int* counter, float* dgamma, float* dbeta, int replicas, unsigned int* timeouts) {
   constexpr int EG = Granule<T>::N;
-  extern __shared__ float red[];             // 2 * C (block_channel_flush, then the totals)
+  extern __shared__ acc_t lds_acc[];         // 2 * C accumulators (block_channel_flush), then the totals as floats
+  float* red = reinterpret_cast<float*>(lds_acc);
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
   float m[EG], is[EG], ga[EG], be[EG];
@@ -581,8 +592,8 @@ __global__ __launch_bounds__(kThreads, 3) void bn_bwd_onepass_kernel(
       acc[1][e] += d * xh;
     }
   }
-  float* outs[2] = {sum_dy, sum_dy_xhat};
-  block_channel_flush<2, EG, true>(acc, C, cg, outs, replicas);
+  acc_t* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG, KD6D_DET_GRAD, true>(acc, C, cg, outs, replicas);
   grid_barrier(counter, gridDim.x, timeouts);
   // only the RAW slice crosses the barrier: without this the compiler also keeps xhat and the masked gradient of
   // the first phase alive (twice the registers, half the resident workgroups)
@@ -632,10 +643,11 @@ template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
     const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int items, int per_thread, int H, int W,
     int C, float inv_rows, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dy, float* sum_dy_xhat,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, acc_t* sum_dy, acc_t* sum_dy_xhat,
     unsigned int* counter, float* dgamma, float* dbeta, int replicas, unsigned int* timeouts) {
   constexpr int EG = Granule<T>::N;
-  extern __shared__ float red[];
+  extern __shared__ acc_t lds_acc[];         // 2 * C accumulators (block_channel_flush), then the totals as floats
+  float* red = reinterpret_cast<float*>(lds_acc);
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
   float m[EG], is[EG], ga[EG], be[EG], sc[EG], sh[EG];
@@ -674,8 +686,8 @@ __global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
       acc[1][e] += d * xa;
     }
   }
-  float* outs[2] = {sum_dy, sum_dy_xhat};
-  block_channel_flush<2, EG, true>(acc, C, cg, outs, replicas);
+  acc_t* outs[2] = {sum_dy, sum_dy_xhat};
+  block_channel_flush<2, EG, KD6D_DET_GRAD, true>(acc, C, cg, outs, replicas);
   grid_barrier(counter, gridDim.x, timeouts);
   replica_totals(sum_dy, sum_dy_xhat, C, replicas, red);
   float k1[EG], k2[EG];
@@ -712,8 +724,8 @@ __global__ __launch_bounds__(kThreads, 3) void bn_pool_bwd_onepass_kernel(
 
 // ---------------------------------------------------------------------------
 // GroupNorm(G) + ReLU over multi-level NHWC tensors.  Statistics are kept as RAW sums
-// stats[(seg*batch + b)*G + g] = {sum x, sum x^2} (fp32 atomics from row-chunk workgroups,
-// so a 32x32 level is reduced by 16 workgroups instead of one); consumers derive
+// stats[(seg*batch + b)*G + g] = {sum x, sum x^2}, two accumulators (kd6d_det.h; integer atomics from row-chunk
+// workgroups, so a 32x32 level is reduced by 16 workgroups instead of one); consumers derive
 // mean = s/n, rstd = rsqrt(max(q/n - mean^2, 0) + eps) with n = H*W*C/G.
 // ---------------------------------------------------------------------------
 // rows of one (level, sample) handled by a reduction workgroup (GnGeom::chunk_rows)
@@ -745,21 +757,22 @@ __device__ __forceinline__ void gn_chunk(const GnGeom& gm, int blk, int& seg, in
   r_begin = row0 + b * hw + lo;
 }
 
-__device__ __forceinline__ void gn_mean_rstd(const float* __restrict__ st, float inv_n, float eps, float& mu,
+// st: the {sum, sumsq} accumulator pair of one (level, image, group)
+__device__ __forceinline__ void gn_mean_rstd(const acc_t* __restrict__ st, float inv_n, float eps, float& mu,
                                              float& rs) {
-  mu = st[0] * inv_n;
-  rs = rsqrtf(fmaxf(st[1] * inv_n - mu * mu, 0.f) + eps);
+  mu = det_read<KD6D_DET_ACT>(st) * inv_n;
+  rs = rsqrtf(fmaxf(det_read<KD6D_DET_ACT>(st + 2) * inv_n - mu * mu, 0.f) + eps);
 }
 
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict__ x, GnGeom gm,
-                                                            float* __restrict__ stats) {
+                                                            acc_t* __restrict__ stats) {
   constexpr int EG = Granule<T>::N;
-  __shared__ float s_sum[64], s_sq[64];
+  __shared__ acc_t s_st[64 * 4];           // per group {sum, sumsq} accumulators
   int seg, b, r_begin, r_cnt;
   gn_chunk(gm, blockIdx.x, seg, b, r_begin, r_cnt);
   const int C = gm.C, G = gm.G, cpg = C / G;
-  if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
+  s_st[threadIdx.x] = 0;                   // kThreads == 64 * 4
   __syncthreads();
   const int cgs = C / EG;
   const long long ngran = (long long)r_cnt * cgs;
@@ -776,17 +789,26 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const TX* __restrict
 #pragma unroll
     for (int e = 0; e < EG; ++e) { a1[e] += v[e]; a2[e] += v[e] * v[e]; }
   }
+  // the channels of one group a lane owns are added in registers first (fixed order), then one LDS add per group
 #pragma unroll
-  for (int e = 0; e < EG; ++e) {
-    const int grp = (cg * EG + e) / cpg;
-    atomicAdd(&s_sum[grp], a1[e]);
-    atomicAdd(&s_sq[grp], a2[e]);
+  for (int e0 = 0; e0 < EG; e0 += 4) {
+    if ((cpg & 3) == 0) {
+      const int grp = (cg * EG + e0) / cpg;
+      det_add_lds<KD6D_DET_ACT>(&s_st[grp * 4], (a1[e0] + a1[e0 + 1]) + (a1[e0 + 2] + a1[e0 + 3]));
+      det_add_lds<KD6D_DET_ACT>(&s_st[grp * 4 + 2], (a2[e0] + a2[e0 + 1]) + (a2[e0 + 2] + a2[e0 + 3]));
+    } else {
+#pragma unroll
+      for (int e = e0; e < e0 + 4; ++e) {
+        const int grp = (cg * EG + e) / cpg;
+        det_add_lds<KD6D_DET_ACT>(&s_st[grp * 4], a1[e]);
+        det_add_lds<KD6D_DET_ACT>(&s_st[grp * 4 + 2], a2[e]);
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x < G) {
-    float* o = stats + ((size_t)(seg * gm.batch + b) * G + threadIdx.x) * 2;
-    atomicAdd(o, s_sum[threadIdx.x]);
-    atomicAdd(o + 1, s_sq[threadIdx.x]);
+  if (threadIdx.x < 2 * G) {               // one {lo, hi} pair per thread
+    acc_t* o = stats + ((size_t)(seg * gm.batch + b) * G) * 4 + threadIdx.x * 2;
+    det_add_words(o, s_st[threadIdx.x * 2], s_st[threadIdx.x * 2 + 1]);
   }
 }
 
@@ -802,7 +824,7 @@ __device__ __forceinline__ void gn_locate(const GnGeom& gm, long long row, int& 
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
     const TX* __restrict__ x, T* __restrict__ y, GnGeom gm, long long ngran, float eps,
-    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const acc_t* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta) {
   constexpr int EG = Granule<T>::N;
   const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
@@ -818,14 +840,14 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
     int seg, b, hw;
     gn_locate(gm, row, seg, b, hw);
     const float inv_n = 1.f / ((float)hw * (float)cpg);
-    const float* st = stats + ((size_t)(seg * gm.batch + b) * G) * 2;
+    const acc_t* st = stats + ((size_t)(seg * gm.batch + b) * G) * 4;
     float v[EG];
     load_x<TX, EG>(x, g, v);
     constexpr int NG = 2;                 // a granule touches at most 2 groups (cpg >= EG/2)
     const int g0 = (cg * EG) / cpg;
     float mu[NG], rs[NG];
 #pragma unroll
-    for (int k = 0; k < NG; ++k) gn_mean_rstd(st + min(g0 + k, G - 1) * 2, inv_n, eps, mu[k], rs[k]);
+    for (int k = 0; k < NG; ++k) gn_mean_rstd(st + min(g0 + k, G - 1) * 4, inv_n, eps, mu[k], rs[k]);
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
       const int k = (cg * EG + e) / cpg - g0;
@@ -837,15 +859,71 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
 }
 
 // backward reduce over row chunks:
-//   gsum[(seg,b,g)] += {sum(dy*gamma), sum(dy*gamma*xhat)}; dgamma/dbeta via atomics.
+//   gsum[(seg,b,g)] += {sum(dy*gamma), sum(dy*gamma*xhat)} (accumulators); dgamma / dbeta: accumulators of the gradient
+//   bucket in its PLANAR layout (word lo of channel c at dgamma[c], hi at dgamma[c + acc_hi]; kd6d.h).
+// Inside the workgroup the partial sums of a channel / a group meet in LDS accumulators (dynamic LDS: 2 * C of them).
+template <int EG>
+__device__ __forceinline__ void gn_bwd_block_sums(float (&a_dy)[EG], float (&a_dyx)[EG], const float (&ga)[EG], int C,
+                                                  int cpg, int cgs, int cg, acc_t* red, acc_t* s_ab) {
+  // lanes l, l + cgs, l + 2 cgs ... of a wave own the same channel granule (cgs = 16 or 32 here): fold them
+  // with shuffles first (a fixed order) -- fewer same-address LDS atomics
+  const bool fold = (cgs == 16 || cgs == 32);
+  if (fold) {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      a_dy[e] += __shfl_xor(a_dy[e], 32, 64);
+      a_dyx[e] += __shfl_xor(a_dyx[e], 32, 64);
+      if (cgs == 16) {
+        a_dy[e] += __shfl_xor(a_dy[e], 16, 64);
+        a_dyx[e] += __shfl_xor(a_dyx[e], 16, 64);
+      }
+    }
+  }
+  if (!fold || (int)(threadIdx.x & 63) < cgs) {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int c = cg * EG + e;
+      det_add_lds<KD6D_DET_GRAD>(&red[c * 2], a_dy[e]);
+      det_add_lds<KD6D_DET_GRAD>(&red[(C + c) * 2], a_dyx[e]);
+    }
+    // group sums: add up the lane's channels of one group in registers first
+#pragma unroll
+    for (int e0 = 0; e0 < EG; e0 += 4) {        // cpg is 4 or a multiple of 4 here -> 4 aligned channels share a group
+      const int c = cg * EG + e0;
+      if ((cpg & 3) == 0) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int e = e0; e < e0 + 4; ++e) { sa += a_dy[e] * ga[e]; sb += a_dyx[e] * ga[e]; }
+        det_add_lds<KD6D_DET_GRAD>(&s_ab[(c / cpg) * 4], sa);
+        det_add_lds<KD6D_DET_GRAD>(&s_ab[(c / cpg) * 4 + 2], sb);
+      } else {
+#pragma unroll
+        for (int e = e0; e < e0 + 4; ++e) {
+          det_add_lds<KD6D_DET_GRAD>(&s_ab[((cg * EG + e) / cpg) * 4], a_dy[e] * ga[e]);
+          det_add_lds<KD6D_DET_GRAD>(&s_ab[((cg * EG + e) / cpg) * 4 + 2], a_dyx[e] * ga[e]);
+        }
+      }
+    }
+  }
+}
+
+// the workgroup's per-channel sums (LDS accumulators) -> the gradient bucket's planar accumulators
+__device__ __forceinline__ void gn_bwd_flush_param_grads(const acc_t* red, int C, acc_t* dgamma, acc_t* dbeta,
+                                                         long long acc_hi) {
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    if (dbeta) det_add_words_planar(dbeta + c, acc_hi, red[c * 2], red[c * 2 + 1]);
+    if (dgamma) det_add_words_planar(dgamma + c, acc_hi, red[(C + c) * 2], red[(C + c) * 2 + 1]);
+  }
+}
+
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
-    const TX* __restrict__ x, const T* __restrict__ dz, GnGeom gm, float eps, const float* __restrict__ stats,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gsum,
-    float* dgamma, float* dbeta) {
+    const TX* __restrict__ x, const T* __restrict__ dz, GnGeom gm, float eps, const acc_t* __restrict__ stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, acc_t* __restrict__ gsum,
+    acc_t* dgamma, acc_t* dbeta, long long acc_hi) {
   constexpr int EG = Granule<T>::N;
-  __shared__ float s_a[64], s_b[64];
-  extern __shared__ float red[];  // 2*C
+  __shared__ acc_t s_ab[64 * 4];  // per group {sum dy*gamma, sum dy*gamma*xhat}
+  extern __shared__ acc_t red[];  // 2*C accumulators
   int seg, b, r_begin, r_cnt;
   gn_chunk(gm, blockIdx.x, seg, b, r_begin, r_cnt);
   int hw = 1;
@@ -854,8 +932,8 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
     if (s == seg) hw = gm.hw[s];
   const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
   const float inv_n = 1.f / ((float)hw * (float)cpg);
-  if (threadIdx.x < 64) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
-  for (int i = threadIdx.x; i < 2 * C; i += kThreads) red[i] = 0.f;
+  s_ab[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < 4 * C; i += kThreads) red[i] = 0;
   __syncthreads();
   const int cg = threadIdx.x % cgs;
   const size_t sb = (size_t)(seg * gm.batch + b) * G;
@@ -864,7 +942,7 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     ga[e] = gamma[c]; be[e] = beta[c];
-    gn_mean_rstd(stats + (sb + c / cpg) * 2, inv_n, eps, mu[e], rs[e]);
+    gn_mean_rstd(stats + (sb + c / cpg) * 4, inv_n, eps, mu[e], rs[e]);
   }
   float a_dy[EG], a_dyx[EG];
 #pragma unroll
@@ -887,56 +965,13 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
       a_dyx[e] += d * xh;
     }
   }
-  // lanes l, l + cgs, l + 2 cgs ... of a wave own the same channel granule (cgs = 16 or 32 here): fold them
-  // with shuffles first -- 16- to 64-way same-address LDS float atomics serialise and were the whole cost
-  const bool fold = (cgs == 16 || cgs == 32);
-  if (fold) {
-#pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      a_dy[e] += __shfl_xor(a_dy[e], 32, 64);
-      a_dyx[e] += __shfl_xor(a_dyx[e], 32, 64);
-      if (cgs == 16) {
-        a_dy[e] += __shfl_xor(a_dy[e], 16, 64);
-        a_dyx[e] += __shfl_xor(a_dyx[e], 16, 64);
-      }
-    }
-  }
-  if (!fold || (int)(threadIdx.x & 63) < cgs) {
-#pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      const int c = cg * EG + e;
-      atomicAdd(&red[c], a_dy[e]);
-      atomicAdd(&red[C + c], a_dyx[e]);
-    }
-    // group sums: add up the lane's channels of one group in registers first
-#pragma unroll
-    for (int e0 = 0; e0 < EG; e0 += 4) {        // cpg is 4 or a multiple of 4 here -> 4 aligned channels share a group
-      const int c = cg * EG + e0;
-      float sa = 0.f, sb = 0.f;
-#pragma unroll
-      for (int e = e0; e < e0 + 4; ++e) { sa += a_dy[e] * ga[e]; sb += a_dyx[e] * ga[e]; }
-      if ((cpg & 3) == 0) {
-        atomicAdd(&s_a[c / cpg], sa);
-        atomicAdd(&s_b[c / cpg], sb);
-      } else {
-#pragma unroll
-        for (int e = e0; e < e0 + 4; ++e) {
-          atomicAdd(&s_a[(cg * EG + e) / cpg], a_dy[e] * ga[e]);
-          atomicAdd(&s_b[(cg * EG + e) / cpg], a_dyx[e] * ga[e]);
-        }
-      }
-    }
-  }
+  gn_bwd_block_sums<EG>(a_dy, a_dyx, ga, C, cpg, cgs, cg, red, s_ab);
   __syncthreads();
-  if (threadIdx.x < G) {
-    float* o = gsum + (sb + threadIdx.x) * 2;
-    atomicAdd(o, s_a[threadIdx.x]);
-    atomicAdd(o + 1, s_b[threadIdx.x]);
+  if (threadIdx.x < 2 * G) {
+    acc_t* o = gsum + sb * 4 + threadIdx.x * 2;
+    det_add_words(o, s_ab[threadIdx.x * 2], s_ab[threadIdx.x * 2 + 1]);
   }
-  for (int c = threadIdx.x; c < C; c += kThreads) {
-    if (dbeta) atomicAdd(dbeta + c, red[c]);
-    if (dgamma) atomicAdd(dgamma + c, red[C + c]);
-  }
+  gn_bwd_flush_param_grads(red, C, dgamma, dbeta, acc_hi);
 }
 
 // GN+ReLU backward in ONE pass: the workgroup keeps its row chunk (<= kGnHold granules per thread) in registers,
@@ -948,11 +983,11 @@ constexpr int kGnHold = 8;
 template <typename T, typename TX>
 __device__ __forceinline__ void gn_relu_bwd_onepass_body(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, const GnGeom& gm, float eps,
-    const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* gsum, unsigned int* counters, float* dgamma, float* dbeta, int bid) {
+    const acc_t* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    acc_t* gsum, unsigned int* counters, acc_t* dgamma, acc_t* dbeta, long long acc_hi, int bid) {
   constexpr int EG = Granule<T>::N;
-  __shared__ float s_a[64], s_b[64];
-  extern __shared__ float red[];  // 2*C
+  __shared__ acc_t s_ab[64 * 4];
+  extern __shared__ acc_t red[];  // 2*C accumulators
   int seg, b, r_begin, r_cnt;
   gn_chunk(gm, bid, seg, b, r_begin, r_cnt);
   int hw = 1;
@@ -961,8 +996,8 @@ __device__ __forceinline__ void gn_relu_bwd_onepass_body(
     if (s == seg) hw = gm.hw[s];
   const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
   const float inv_n = 1.f / ((float)hw * (float)cpg);
-  if (threadIdx.x < 64) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
-  for (int i = threadIdx.x; i < 2 * C; i += kThreads) red[i] = 0.f;
+  s_ab[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < 4 * C; i += kThreads) red[i] = 0;
   __syncthreads();
   const int cg = threadIdx.x % cgs;
   const size_t sb = (size_t)(seg * gm.batch + b) * G;
@@ -971,7 +1006,7 @@ __device__ __forceinline__ void gn_relu_bwd_onepass_body(
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     ga[e] = gamma[c]; be[e] = beta[c];
-    gn_mean_rstd(stats + (sb + c / cpg) * 2, inv_n, eps, mu[e], rs[e]);
+    gn_mean_rstd(stats + (sb + c / cpg) * 4, inv_n, eps, mu[e], rs[e]);
   }
   float a_dy[EG], a_dyx[EG];
 #pragma unroll
@@ -1001,43 +1036,30 @@ __device__ __forceinline__ void gn_relu_bwd_onepass_body(
       a_dyx[e] += d * xh;
     }
   }
-  const bool fold = (cgs == 16 || cgs == 32);
-  if (fold) {
-#pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      a_dy[e] += __shfl_xor(a_dy[e], 32, 64);
-      a_dyx[e] += __shfl_xor(a_dyx[e], 32, 64);
-      if (cgs == 16) {
-        a_dy[e] += __shfl_xor(a_dy[e], 16, 64);
-        a_dyx[e] += __shfl_xor(a_dyx[e], 16, 64);
-      }
-    }
-  }
-  if (!fold || (int)(threadIdx.x & 63) < cgs) {
-#pragma unroll
-    for (int e = 0; e < EG; ++e) {
-      const int c = cg * EG + e;
-      atomicAdd(&red[c], a_dy[e]);
-      atomicAdd(&red[C + c], a_dyx[e]);
-      atomicAdd(&s_a[c / cpg], a_dy[e] * ga[e]);
-      atomicAdd(&s_b[c / cpg], a_dyx[e] * ga[e]);
-    }
-  }
+  gn_bwd_block_sums<EG>(a_dy, a_dyx, ga, C, cpg, cgs, cg, red, s_ab);
   __syncthreads();
-  if (threadIdx.x < G) {
-    float* o = gsum + (sb + threadIdx.x) * 2;
-    atomic_add_performed(o, s_a[threadIdx.x]);
-    atomic_add_performed(o + 1, s_b[threadIdx.x]);
+  if (threadIdx.x < 2 * G) {
+    acc_t* o = gsum + sb * 4 + threadIdx.x * 2;
+    det_add_words_performed(o, s_ab[threadIdx.x * 2], s_ab[threadIdx.x * 2 + 1]);
   }
   // (the dgamma / dbeta atomics -- every workgroup of the launch on the same C addresses -- wait until the end:
   //  the siblings do not need them and the barrier would otherwise sit behind that queue)
   group_barrier(counters + seg * gm.batch + b, (unsigned)((hw + gm.chunk_rows - 1) / gm.chunk_rows), gm.timeouts);
   float k1[EG], k2[EG];
 #pragma unroll
-  for (int e = 0; e < EG; ++e) {
-    const float* o = gsum + (sb + (cg * EG + e) / cpg) * 2;
-    k1[e] = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_n;
-    k2[e] = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_n;
+  for (int e0 = 0; e0 < EG; e0 += 4) {           // 4 aligned channels share a group when cpg % 4 == 0
+#pragma unroll
+    for (int e = e0; e < e0 + 4; ++e) {
+      if (e == e0 || (cpg & 3) != 0) {
+        const acc_t* o = gsum + (sb + (cg * EG + e) / cpg) * 4;
+        const det_words w1 = det_load_device_scope(o), w2 = det_load_device_scope(o + 2);
+        k1[e] = det_value<KD6D_DET_GRAD>(w1.lo, w1.hi) * inv_n;
+        k2[e] = det_value<KD6D_DET_GRAD>(w2.lo, w2.hi) * inv_n;
+      } else {
+        k1[e] = k1[e0];
+        k2[e] = k2[e0];
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < kGnHold; ++i) {
@@ -1049,18 +1071,15 @@ __device__ __forceinline__ void gn_relu_bwd_onepass_body(
       og[g] = f32_to_granule<T>(o);
     }
   }
-  for (int c = threadIdx.x; c < C; c += kThreads) {
-    if (dbeta) atomicAdd(dbeta + c, red[c]);
-    if (dgamma) atomicAdd(dgamma + c, red[C + c]);
-  }
+  gn_bwd_flush_param_grads(red, C, dgamma, dbeta, acc_hi);
 }
 
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm, float eps,
-    const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* gsum, unsigned int* counters, float* dgamma, float* dbeta) {
-  gn_relu_bwd_onepass_body<T, TX>(x, dz, dx, gm, eps, stats, gamma, beta, gsum, counters, dgamma, dbeta, blockIdx.x);
+    const acc_t* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    acc_t* gsum, unsigned int* counters, acc_t* dgamma, acc_t* dbeta, long long acc_hi) {
+  gn_relu_bwd_onepass_body<T, TX>(x, dz, dx, gm, eps, stats, gamma, beta, gsum, counters, dgamma, dbeta, acc_hi, blockIdx.x);
 }
 
 // Two GroupNorm backwards of identical geometry (the cls and the pose tower layer of the head) as ONE launch:
@@ -1068,21 +1087,22 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_kernel(
 // 4 waves on 256 CUs and latency-bound; back to back on one stream the second waited for the first.
 struct GnBwdSet {
   const void* x; const void* dz; void* dx;
-  const float* stats; const float* gamma; const float* beta;
-  float* gsum; unsigned int* counters; float* dgamma; float* dbeta;
+  const acc_t* stats; const float* gamma; const float* beta;
+  acc_t* gsum; unsigned int* counters; acc_t* dgamma; acc_t* dbeta;
 };
 template <typename T, typename TX>
-__global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_pair_kernel(GnBwdSet a, GnBwdSet b, GnGeom gm, float eps) {
+__global__ __launch_bounds__(kThreads) void gn_relu_bwd_onepass_pair_kernel(GnBwdSet a, GnBwdSet b, GnGeom gm, float eps,
+                                                                            long long acc_hi) {
   const bool first = (int)blockIdx.x < gm.nblk;
   const GnBwdSet& q = first ? a : b;
   gn_relu_bwd_onepass_body<T, TX>((const TX*)q.x, (const T*)q.dz, (T*)q.dx, gm, eps, q.stats, q.gamma, q.beta, q.gsum,
-                                  q.counters, q.dgamma, q.dbeta, first ? blockIdx.x : blockIdx.x - gm.nblk);
+                                  q.counters, q.dgamma, q.dbeta, acc_hi, first ? blockIdx.x : blockIdx.x - gm.nblk);
 }
 
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
     const TX* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx, GnGeom gm,
-    long long ngran, float eps, const float* __restrict__ stats, const float* __restrict__ gsum,
+    long long ngran, float eps, const acc_t* __restrict__ stats, const acc_t* __restrict__ gsum,
     const float* __restrict__ gamma, const float* __restrict__ beta) {
   constexpr int EG = Granule<T>::N;
   const int C = gm.C, G = gm.G, cpg = C / G, cgs = C / EG;
@@ -1109,9 +1129,9 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int gi = min(g0 + k, G - 1);
-      gn_mean_rstd(stats + (sb + gi) * 2, inv_n, eps, mu[k], rs[k]);
-      k1[k] = gsum[(sb + gi) * 2] * inv_n;
-      k2[k] = gsum[(sb + gi) * 2 + 1] * inv_n;
+      gn_mean_rstd(stats + (sb + gi) * 4, inv_n, eps, mu[k], rs[k]);
+      k1[k] = det_read<KD6D_DET_GRAD>(gsum + (sb + gi) * 4) * inv_n;
+      k2[k] = det_read<KD6D_DET_GRAD>(gsum + (sb + gi) * 4 + 2) * inv_n;
     }
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
@@ -1403,11 +1423,17 @@ long long gn_rows(const GnGeom& gm) {
 
 }  // namespace
 
+namespace kd6d_detail {
+int colsum_grad_planar(int dtype, const void* x, int64_t rows, int C, long long* acc, long long acc_hi, void* stream);
+}
+
 #define DISPATCH_T(dtype, expr_bf16, expr_f32) \
   do { if ((dtype) == KD6D_BF16) { expr_bf16; } else { expr_f32; } } while (0)
 
-extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, float* sum,
-                             float* sumsq, void* stream) {
+extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, kd6d_acc* sum_acc,
+                             kd6d_acc* sumsq_acc, void* stream) {
+  acc_t* sum = reinterpret_cast<acc_t*>(sum_acc);
+  acc_t* sumsq = reinterpret_cast<acc_t*>(sumsq_acc);
   KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "kd6d_colstats: bad dtype %d", dtype);
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   KD6D_CHECK_ARG(C > 0 && C % eg == 0 && C / eg <= kThreads, "kd6d_colstats: C=%d must be a multiple of %d and <= %d",
@@ -1418,13 +1444,35 @@ extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, floa
   long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
   if (nb > kColstatsCap) nb = kColstatsCap;
   if (nb < 1) nb = 1;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((int)nb), dim3(kThreads), lds, st,
-                                (const bf16_t*)x, (long long)rows, C, sum, sumsq),
+                                (const bf16_t*)x, (long long)rows, C, sum, sumsq, 0ll),
              hipLaunchKernelGGL(colstats_kernel<float>, dim3((int)nb), dim3(kThreads), lds, st,
-                                (const float*)x, (long long)rows, C, sum, sumsq));
+                                (const float*)x, (long long)rows, C, sum, sumsq, 0ll));
   KD6D_CHECK_LAUNCH("kd6d_colstats");
+  return KD6D_OK;
+}
+
+// conv_igemm.hip (exact-fp32 weight gradient): the bias gradient as a separate column-sum pass
+int kd6d_detail::colsum_grad_planar(int dtype, const void* x, int64_t rows, int C, long long* acc, long long acc_hi,
+                                    void* stream) {
+  KD6D_CHECK_ARG(dtype == KD6D_BF16 || dtype == KD6D_F32, "colsum_grad_planar: bad dtype %d", dtype);
+  const int eg = dtype == KD6D_BF16 ? 8 : 4;
+  KD6D_CHECK_ARG(C > 0 && C % eg == 0 && C / eg <= kThreads && x && acc && rows > 0, "colsum_grad_planar: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpp = kThreads / (C / eg);
+  long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
+  if (nb > kColstatsCap) nb = kColstatsCap;
+  if (nb < 1) nb = 1;
+  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  acc_t* none = nullptr;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((colstats_kernel<bf16_t, true>), dim3((int)nb), dim3(kThreads), lds, st,
+                                (const bf16_t*)x, (long long)rows, C, acc, none, acc_hi),
+             hipLaunchKernelGGL((colstats_kernel<float, true>), dim3((int)nb), dim3(kThreads), lds, st,
+                                (const float*)x, (long long)rows, C, acc, none, acc_hi));
+  KD6D_CHECK_LAUNCH("colsum_grad_planar");
   return KD6D_OK;
 }
 
@@ -1436,12 +1484,14 @@ extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, floa
   } while (0)
 
 extern "C" int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, int64_t rows, int C,
-                                 const float* sum, const float* sumsq, const float* gamma,
+                                 const kd6d_acc* sum_acc, const kd6d_acc* sumsq_acc, const float* gamma,
                                  const float* beta, float eps, float momentum, float* running_mean,
                                  float* running_var, float* save_mean, float* save_invstd, int act,
                                  void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_fwd");
   if (rc) return rc;
+  const acc_t* sum = reinterpret_cast<const acc_t*>(sum_acc);
+  const acc_t* sumsq = reinterpret_cast<const acc_t*>(sumsq_acc);
   KD6D_CHECK_ARG(x && y && sum && sumsq && gamma && beta && rows > 0, "kd6d_bn_train_fwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
@@ -1459,10 +1509,12 @@ extern "C" int kd6d_bn_train_fwd(int dtype, int x_f32, const void* x, void* y, i
 
 extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, const void* dz, int64_t rows,
                                         int C, const float* mean, const float* invstd, const float* gamma,
-                                        const float* beta, int act, float* sum_dy, float* sum_dy_xhat,
+                                        const float* beta, int act, kd6d_acc* sum_dy_acc, kd6d_acc* sum_dy_xhat_acc,
                                         int replicas, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_reduce");
   if (rc) return rc;
+  acc_t* sum_dy = reinterpret_cast<acc_t*>(sum_dy_acc);
+  acc_t* sum_dy_xhat = reinterpret_cast<acc_t*>(sum_dy_xhat_acc);
   KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_train_bwd_reduce: replicas=%d outside [1,64]", replicas);
   KD6D_CHECK_ARG(x && dz && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
                  "kd6d_bn_train_bwd_reduce: bad arguments");
@@ -1474,7 +1526,7 @@ extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, con
   long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
   if (nb > kBnBwdReduceCap) nb = kBnBwdReduceCap;
   if (nb < 1) nb = 1;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads), lds, st,
                                    (const TX_*)x, (const T_*)dz, ngran, C, mean, invstd, gamma, beta, act, sum_dy,
@@ -1486,10 +1538,12 @@ extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, con
 extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, const void* dz, void* dx,
                                        int64_t rows, int C, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, int act,
-                                       const float* sum_dy, const float* sum_dy_xhat, float* dgamma,
+                                       const kd6d_acc* sum_dy_acc, const kd6d_acc* sum_dy_xhat_acc, float* dgamma,
                                        float* dbeta, int replicas, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_bwd_apply");
   if (rc) return rc;
+  const acc_t* sum_dy = reinterpret_cast<const acc_t*>(sum_dy_acc);
+  const acc_t* sum_dy_xhat = reinterpret_cast<const acc_t*>(sum_dy_xhat_acc);
   KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_train_bwd_apply: replicas=%d outside [1,64]", replicas);
   KD6D_CHECK_ARG(x && dz && dx && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat && rows > 0,
                  "kd6d_bn_train_bwd_apply: bad arguments");
@@ -1502,17 +1556,19 @@ extern "C" int kd6d_bn_train_bwd_apply(int dtype, int x_f32, const void* x, cons
                hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads),
                                    (size_t)2 * C * sizeof(float), st,
                                    (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, C, inv_rows, mean, invstd, gamma,
-                                   beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta, replicas));
+                                   beta, act, sum_dy, sum_dy_xhat, dgamma, dbeta, replicas));   /* LDS: the totals as floats */
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd_apply");
   return KD6D_OK;
 }
 
 extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx, int64_t rows, int C,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                 int act, float* sum_dy, float* sum_dy_xhat, unsigned int* counter, float* dgamma,
+                                 int act, kd6d_acc* sum_dy_acc, kd6d_acc* sum_dy_xhat_acc, unsigned int* counter, float* dgamma,
                                  float* dbeta, int replicas, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_bn_train_bwd");
   if (rc) return rc;
+  acc_t* sum_dy = reinterpret_cast<acc_t*>(sum_dy_acc);
+  acc_t* sum_dy_xhat = reinterpret_cast<acc_t*>(sum_dy_xhat_acc);
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   const long long ngran = rows * (C / eg);
   int cap = 0;
@@ -1521,11 +1577,11 @@ extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void
   if (cap > kBnOnepassBlocks) cap = kBnOnepassBlocks;
   if (!(counter && bn_onepass() && rows > 0 && cap > 0 && ngran <= (long long)cap * kThreads * kBnHold &&
         ngran <= bn_onepass_max_granules())) {
-    rc = kd6d_bn_train_bwd_reduce(dtype, x_f32, x, dz, rows, C, mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat,
+    rc = kd6d_bn_train_bwd_reduce(dtype, x_f32, x, dz, rows, C, mean, invstd, gamma, beta, act, sum_dy_acc, sum_dy_xhat_acc,
                                   replicas, stream);
     if (rc) return rc;
-    return kd6d_bn_train_bwd_apply(dtype, x_f32, x, dz, dx, rows, C, mean, invstd, gamma, beta, act, sum_dy,
-                                   sum_dy_xhat, dgamma, dbeta, replicas, stream);
+    return kd6d_bn_train_bwd_apply(dtype, x_f32, x, dz, dx, rows, C, mean, invstd, gamma, beta, act, sum_dy_acc,
+                                   sum_dy_xhat_acc, dgamma, dbeta, replicas, stream);
   }
   KD6D_CHECK_ARG(replicas >= 1 && replicas <= 64, "kd6d_bn_train_bwd: replicas=%d outside [1,64]", replicas);
   KD6D_CHECK_ARG(x && dz && dx && mean && invstd && gamma && beta && sum_dy && sum_dy_xhat,
@@ -1537,7 +1593,7 @@ extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void
   const float inv_rows = 1.f / (float)rows;
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((bn_bwd_onepass_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads),
-                                  (size_t)2 * C * sizeof(float), st, (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, per,
+                                  (size_t)2 * C * sizeof(kd6d_acc), st, (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, per,
                                   C, inv_rows, mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma,
                                   dbeta, replicas, kd6d_ctx_timeouts_ptr()));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd");
@@ -1565,10 +1621,12 @@ static int check_pool(int dtype, int B, int H, int W, int C, const char* who, lo
 }
 
 extern "C" int kd6d_bn_pool_train_fwd(int dtype, int x_f32, const void* x, void* y, int B, int H, int W, int C,
-                                      const float* sum, const float* sumsq, const float* gamma,
+                                      const kd6d_acc* sum_acc, const kd6d_acc* sumsq_acc, const float* gamma,
                                       const float* beta, float eps, float momentum, float* running_mean,
                                       float* running_var, float* save_mean, float* save_invstd, int act,
                                       void* stream) {
+  const acc_t* sum = reinterpret_cast<const acc_t*>(sum_acc);
+  const acc_t* sumsq = reinterpret_cast<const acc_t*>(sumsq_acc);
   long long items = 0;
   int rc = check_pool(dtype, B, H, W, C, "kd6d_bn_pool_train_fwd", &items);
   if (rc) return rc;
@@ -1588,9 +1646,11 @@ extern "C" int kd6d_bn_pool_train_fwd(int dtype, int x_f32, const void* x, void*
 
 extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const void* dy, void* dx, int B, int H,
                                       int W, int C, const float* mean, const float* invstd, const float* gamma,
-                                      const float* beta, int act, float* sum_dy, float* sum_dy_xhat,
+                                      const float* beta, int act, kd6d_acc* sum_dy_acc, kd6d_acc* sum_dy_xhat_acc,
                                       unsigned int* counter, float* dgamma, float* dbeta, int replicas,
                                       void* stream) {
+  acc_t* sum_dy = reinterpret_cast<acc_t*>(sum_dy_acc);
+  acc_t* sum_dy_xhat = reinterpret_cast<acc_t*>(sum_dy_xhat_acc);
   long long items = 0;
   int rc = check_pool(dtype, B, H, W, C, "kd6d_bn_pool_train_bwd", &items);
   if (rc) return rc;
@@ -1603,7 +1663,7 @@ extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const
   if (nbr > kBnBwdReduceCap) nbr = kBnBwdReduceCap;
   if (nbr < 1) nbr = 1;
   const int nba = grid_for(items);
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
   int cap = 0;
   DISPATCH_TTX(dtype, x_f32, cap = (bn_onepass_capacity<T_, TX_>(true)));
   cap = cap * 3 / 4;                                      // the whole grid must be resident for the barrier
@@ -1635,9 +1695,10 @@ extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const
 
 extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, const int32_t* level_hw_host,
                                 int nseg, int batch, int C, int groups, const float* gamma,
-                                const float* beta, float eps, float* stats, int flags, void* stream) {
+                                const float* beta, float eps, kd6d_acc* stats_acc, int flags, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_gn_relu_fwd");
   if (rc) return rc;
+  acc_t* stats = reinterpret_cast<acc_t*>(stats_acc);
   GnGeom gm;
   KD6D_CHECK_ARG(level_hw_host && fill_gn(level_hw_host, nseg, batch, C, groups, &gm),
                  "kd6d_gn_relu_fwd: bad level table / groups");
@@ -1649,7 +1710,7 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, co
   KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_fwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
   const bool ready = flags & KD6D_GN_STATS_READY;
   if (!ready && !(flags & KD6D_GN_WS_ZEROED) &&
-      hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
+      hipMemsetAsync(stats, 0, sizeof(kd6d_acc) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
     kd6d_set_error("kd6d_gn_relu_fwd: memset failed");
     return KD6D_ERR_LAUNCH;
   }
@@ -1665,10 +1726,17 @@ extern "C" int kd6d_gn_relu_fwd(int dtype, int x_f32, const void* x, void* y, co
 
 extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void* dz, void* dx,
                                 const int32_t* level_hw_host, int nseg, int batch, int C, int groups,
-                                const float* gamma, const float* beta, float eps, const float* stats,
-                                float* gsum_ws, float* dgamma, float* dbeta, int flags, void* stream) {
+                                const float* gamma, const float* beta, float eps, const kd6d_acc* stats_acc,
+                                kd6d_acc* gsum_ws_acc, int64_t* dgamma_acc, int64_t* dbeta_acc, int64_t acc_hi_stride,
+                                int flags, void* stream) {
   int rc = check_channels(dtype, C, "kd6d_gn_relu_bwd");
   if (rc) return rc;
+  const acc_t* stats = reinterpret_cast<const acc_t*>(stats_acc);
+  acc_t* gsum_ws = reinterpret_cast<acc_t*>(gsum_ws_acc);
+  acc_t* dgamma = reinterpret_cast<acc_t*>(dgamma_acc);
+  acc_t* dbeta = reinterpret_cast<acc_t*>(dbeta_acc);
+  const long long acc_hi = (long long)acc_hi_stride;
+  KD6D_CHECK_ARG((!dgamma && !dbeta) || acc_hi_stride != 0, "kd6d_gn_relu_bwd: acc_hi_stride = 0 with gradient accumulators");
   GnGeom gm;
   KD6D_CHECK_ARG(level_hw_host && fill_gn(level_hw_host, nseg, batch, C, groups, &gm),
                  "kd6d_gn_relu_bwd: bad level table / groups");
@@ -1677,10 +1745,10 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
   KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_bwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
   if (!(flags & KD6D_GN_WS_ZEROED) &&
-      hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
+      hipMemsetAsync(gsum_ws, 0, sizeof(kd6d_acc) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
     kd6d_set_error("kd6d_gn_relu_bwd: memset failed");
     return KD6D_ERR_LAUNCH;
   }
@@ -1696,7 +1764,7 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
     for (int s = 0; s < nseg; ++s) gmax = g1.cps[s] > gmax ? g1.cps[s] : gmax;
     KD6D_CHECK_ARG(gcap >= 2 * gmax, "kd6d_gn_relu_bwd: a level of %d row chunks does not fit the %d resident workgroups "
                    "(set option gn.onepass = 0)", gmax, gcap);
-    unsigned int* counters = reinterpret_cast<unsigned int*>(gsum_ws + 2 * (size_t)nseg * batch * groups);
+    unsigned int* counters = reinterpret_cast<unsigned int*>(gsum_ws + 4 * (size_t)nseg * batch * groups);
     if (!(flags & KD6D_GN_WS_ZEROED) &&
         hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)nseg * batch, st) != hipSuccess) {
       kd6d_set_error("kd6d_gn_relu_bwd: memset failed");
@@ -1705,13 +1773,13 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
     DISPATCH_TTX(dtype, x_f32,
                  hipLaunchKernelGGL((gn_relu_bwd_onepass_kernel<T_, TX_>), dim3(g1.nblk), dim3(kThreads), lds, st,
                                     (const TX_*)x, (const T_*)dz, (T_*)dx, g1, eps, stats, gamma, beta, gsum_ws,
-                                    counters, dgamma, dbeta));
+                                    counters, dgamma, dbeta, acc_hi));
     KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd");
     return KD6D_OK;
   }
   DISPATCH_TTX(dtype, x_f32, {
     hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<T_, TX_>), dim3(gm.nblk), dim3(kThreads), lds, st,
-                       (const TX_*)x, (const T_*)dz, gm, eps, stats, gamma, beta, gsum_ws, dgamma, dbeta);
+                       (const TX_*)x, (const T_*)dz, gm, eps, stats, gamma, beta, gsum_ws, dgamma, dbeta, acc_hi);
     hipLaunchKernelGGL((gn_relu_bwd_apply_kernel<T_, TX_>), dim3(nb), dim3(kThreads), 0, st, (const TX_*)x,
                        (const T_*)dz, (T_*)dx, gm, ngran, eps, stats, gsum_ws, gamma, beta);
   });
@@ -1721,7 +1789,7 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
 
 extern "C" int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a, const kd6d_gn_item* b,
                                      const int32_t* level_hw_host, int nseg, int batch, int C, int groups, float eps,
-                                     int flags, void* stream) {
+                                     int64_t acc_hi_stride, int flags, void* stream) {
   KD6D_CHECK_ARG(a && b, "kd6d_gn_relu_bwd_pair: null item");
   // the one-launch form exists for the in-kernel-barrier backward only; everything else goes out one by one
   int chunk = 0;
@@ -1745,7 +1813,7 @@ extern "C" int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a
     for (int i = 0; i < 2; ++i) {
       const int rc = kd6d_gn_relu_bwd(dtype, x_f32, it[i]->x, it[i]->dz, it[i]->dx, level_hw_host, nseg, batch, C, groups,
                                       it[i]->gamma, it[i]->beta, eps, it[i]->stats, it[i]->gsum_ws, it[i]->dgamma,
-                                      it[i]->dbeta, flags, stream);
+                                      it[i]->dbeta, acc_hi_stride, flags, stream);
       if (rc) return rc;
     }
     return KD6D_OK;
@@ -1755,20 +1823,23 @@ extern "C" int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a
   for (int i = 0; i < 2; ++i) {
     KD6D_CHECK_ARG(it[i]->x && it[i]->dz && it[i]->dx && it[i]->gamma && it[i]->beta && it[i]->stats && it[i]->gsum_ws,
                    "kd6d_gn_relu_bwd_pair: null pointer in item %d", i);
-    unsigned int* counters = reinterpret_cast<unsigned int*>(it[i]->gsum_ws + 2 * (size_t)nseg * batch * groups);
+    KD6D_CHECK_ARG((!it[i]->dgamma && !it[i]->dbeta) || acc_hi_stride != 0,
+                   "kd6d_gn_relu_bwd_pair: acc_hi_stride = 0 with gradient accumulators");
+    unsigned int* counters = reinterpret_cast<unsigned int*>(it[i]->gsum_ws + 2 * (size_t)nseg * batch * groups);   // kd6d_acc units
     if (!(flags & KD6D_GN_WS_ZEROED) &&
-        hipMemsetAsync(it[i]->gsum_ws, 0, sizeof(float) * 2 * (size_t)nseg * batch * groups + sizeof(unsigned int) * (size_t)nseg * batch,
+        hipMemsetAsync(it[i]->gsum_ws, 0, sizeof(kd6d_acc) * 2 * (size_t)nseg * batch * groups + sizeof(unsigned int) * (size_t)nseg * batch,
                        st) != hipSuccess) {
       kd6d_set_error("kd6d_gn_relu_bwd_pair: memset failed");
       return KD6D_ERR_LAUNCH;
     }
-    sets[i] = GnBwdSet{it[i]->x, it[i]->dz, it[i]->dx, it[i]->stats, it[i]->gamma, it[i]->beta, it[i]->gsum_ws, counters,
-                       it[i]->dgamma, it[i]->dbeta};
+    sets[i] = GnBwdSet{it[i]->x, it[i]->dz, it[i]->dx, reinterpret_cast<const acc_t*>(it[i]->stats), it[i]->gamma,
+                       it[i]->beta, reinterpret_cast<acc_t*>(it[i]->gsum_ws), counters,
+                       reinterpret_cast<acc_t*>(it[i]->dgamma), reinterpret_cast<acc_t*>(it[i]->dbeta)};
   }
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((gn_relu_bwd_onepass_pair_kernel<T_, TX_>), dim3(2 * g1.nblk), dim3(kThreads), lds, st,
-                                  sets[0], sets[1], g1, eps));
+                                  sets[0], sets[1], g1, eps, (long long)acc_hi_stride));
   KD6D_CHECK_LAUNCH("kd6d_gn_relu_bwd_pair");
   return KD6D_OK;
 }

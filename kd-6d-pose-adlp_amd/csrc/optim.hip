@@ -6,13 +6,14 @@
 // (sum of squares, then clip + AdamW + optional bf16 shadow refresh), HBM-bound:
 // 16 B read + 12 B (+2 B) written per parameter.
 #include "kd6d_common.h"
+#include "kd6d_det.h"
 
 namespace {
 
 constexpr int kT = 256;
 
 __global__ __launch_bounds__(kT) void sumsq_kernel(const float* __restrict__ x, long long n,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, long long* ws) {
   __shared__ float s_part[kT / 64];
   float acc = 0.f;
   const long long n4 = n >> 2;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(kT) void sumsq_kernel(const float* __restrict__ x, 
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int w = 0; w < kT / 64; ++w) s += s_part[w];
-    atomicAdd(out, s);
+    kd6d_detail::det_scalar_arrive<KD6D_DET_ACT>(ws, s, gridDim.x, out);     // fixed-point accumulator: reproducible
   }
 }
 
@@ -61,12 +62,49 @@ __global__ __launch_bounds__(kT) void clip_adamw_kernel(float* __restrict__ p, c
 
 __global__ void set_hyper_kernel(float* __restrict__ hyper, float lr, float bc1, float bc2_sqrt) {
   hyper[0] = lr; hyper[1] = bc1; hyper[2] = bc2_sqrt; hyper[3] = 0.f;
+  for (int i = 8; i < 16; ++i) hyper[i] = 0.f;          // kd6d_sumsq's workspace (kd6d_scalar_ws)
 }
 
 __global__ __launch_bounds__(kT) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
                                                        long long n) {
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT)
     y[i] = (bf16_t)x[i];
+}
+
+// value of n interleaved accumulators -> fp32 (tests, debugging, stand-alone callers of the statistics kernels)
+template <int E>
+__global__ __launch_bounds__(kT) void acc_read_kernel(long long* __restrict__ acc, long long n, float* __restrict__ out,
+                                                      int accumulate, int clear) {
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+    const float v = kd6d_detail::det_value<E>(acc[2 * i], acc[2 * i + 1]);
+    out[i] = accumulate ? out[i] + v : v;
+    if (clear) { acc[2 * i] = 0; acc[2 * i + 1] = 0; }
+  }
+}
+
+// End of the reverse sweep: the gradient bucket's PLANAR accumulators -> fp32 gradients, accumulators cleared for the
+// next step.  desc: int64 triples {first element, element count, first workgroup}; a workgroup owns 1024 elements.
+__global__ __launch_bounds__(kT) void grad_acc_resolve_kernel(const long long* __restrict__ desc, int n_regions,
+                                                              long long* __restrict__ acc, long long hi_off,
+                                                              float* __restrict__ grads) {
+  int r = 0;
+  for (int i = 1; i < n_regions; ++i)
+    if ((long long)blockIdx.x >= desc[i * 3 + 2]) r = i;
+  const long long first = desc[r * 3], count = desc[r * 3 + 1];
+  const long long base = ((long long)blockIdx.x - desc[r * 3 + 2]) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + k * kT + threadIdx.x;
+    if (i < count) {
+      long long* lo = acc + first + i;
+      const long long l = lo[0], h = lo[hi_off];
+      if (l | h) {
+        grads[first + i] += kd6d_detail::det_value<KD6D_DET_GRAD>(l, h);
+        lo[0] = 0;
+        if (h) lo[hi_off] = 0;
+      }
+    }
+  }
 }
 
 int blocks_for(long long n) {
@@ -78,15 +116,39 @@ int blocks_for(long long n) {
 
 }  // namespace
 
-extern "C" int kd6d_sumsq(const float* x, int64_t n, float* out, void* stream) {
-  KD6D_CHECK_ARG(x && out && n > 0, "kd6d_sumsq: bad arguments");
+extern "C" int kd6d_acc_read(kd6d_acc* acc, int64_t n, int kind, float* out, int accumulate, int clear, void* stream) {
+  KD6D_CHECK_ARG(acc && out && n > 0 && (kind == KD6D_ACC_ACT || kind == KD6D_ACC_GRAD), "kd6d_acc_read: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long long* words = reinterpret_cast<long long*>(acc);
+  const int nb = blocks_for(n * 4);
+  if (kind == KD6D_ACC_ACT)
+    hipLaunchKernelGGL(acc_read_kernel<KD6D_DET_ACT>, dim3(nb), dim3(kT), 0, st, words, (long long)n, out, accumulate, clear);
+  else
+    hipLaunchKernelGGL(acc_read_kernel<KD6D_DET_GRAD>, dim3(nb), dim3(kT), 0, st, words, (long long)n, out, accumulate, clear);
+  KD6D_CHECK_LAUNCH("kd6d_acc_read");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_grad_acc_resolve(const int64_t* desc_dev, int n_regions, int total_blocks, int64_t* acc,
+                                     int64_t acc_hi_stride, float* grads, void* stream) {
+  KD6D_CHECK_ARG(desc_dev && n_regions > 0 && total_blocks > 0 && acc && acc_hi_stride != 0 && grads,
+                 "kd6d_grad_acc_resolve: bad arguments");
+  hipLaunchKernelGGL(grad_acc_resolve_kernel, dim3(total_blocks), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(desc_dev), n_regions, reinterpret_cast<long long*>(acc),
+                     (long long)acc_hi_stride, grads);
+  KD6D_CHECK_LAUNCH("kd6d_grad_acc_resolve");
+  return KD6D_OK;
+}
+
+extern "C" int kd6d_sumsq(const float* x, int64_t n, float* out, kd6d_scalar_ws* ws, void* stream) {
+  KD6D_CHECK_ARG(x && out && ws && n > 0, "kd6d_sumsq: bad arguments");
   KD6D_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "kd6d_sumsq: x must be 16-byte aligned");
   // every workgroup ends with ONE atomic on the same address, and those retire serially (~13-27 ns each): 2048
   // workgroups spent 28 us on a 9-MB gradient bucket, 128 read it in a third of that
   int nb = blocks_for(n);
   if (nb > 128) nb = 128;
   hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     (long long)n, out);
+                     (long long)n, out, reinterpret_cast<long long*>(ws));
   KD6D_CHECK_LAUNCH("kd6d_sumsq");
   return KD6D_OK;
 }

@@ -15,7 +15,8 @@ KD6D_F32 = 1
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 GN_STATS_READY, GN_WS_ZEROED = 1, 2
 MAX_SEG = 5
-ABI_VERSION = 7
+ABI_VERSION = 8
+ACC_ACT, ACC_GRAD = 32, 52           # KD6D_ACC_ACT / KD6D_ACC_GRAD: fixed-point classes of kd6d_acc
 NORM_GROUP, NORM_BATCH = 1, 2
 BN_FUSED_REPLICAS = 8
 NORM_MAX_CTILES = 8
@@ -105,7 +106,9 @@ SIGNATURES = {
     "kd6d_conv2d_fwd_norm_fusable": [_G, _I, _I, _I],
     "kd6d_conv2d_fwd_norm": [_G, _I, _P, _P, _P, _P, ctypes.POINTER(ConvNorm), _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
-    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I, _P],
+    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I64, _I, _P],
+    "kd6d_acc_read": [_P, _I64, _I, _P, _I, _I, _P],
+    "kd6d_grad_acc_resolve": [_P, _I, _I, _P, _I64, _P, _P],
     "kd6d_wgrad_group_supported": [_G, _I],
     "kd6d_wgrad_group_plan": [ctypes.POINTER(WgradItem), _I, _I, _I, _P, _I64, ctypes.POINTER(ctypes.c_int32)],
     "kd6d_wgrad_group_launch": [_P, _I, _I, _P, _P],
@@ -123,9 +126,9 @@ SIGNATURES = {
     "kd6d_bn_train_bwd": [_I, _I, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "kd6d_gn_relu_fwd": [_I, _I, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "kd6d_gn_relu_bwd": [_I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I, _I, _P, _P, _F, _P,
-                         _P, _P, _P, _I, _P],
+                         _P, _P, _P, _I64, _I, _P],
     "kd6d_gn_relu_bwd_pair": [_I, _I, ctypes.POINTER(GnItem), ctypes.POINTER(GnItem), ctypes.POINTER(ctypes.c_int32),
-                              _I, _I, _I, _I, _F, _I, _P],
+                              _I, _I, _I, _I, _F, _I64, _I, _P],
     "kd6d_maxpool2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
     "kd6d_maxpool2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kd6d_upsample2_add": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -140,15 +143,15 @@ SIGNATURES = {
     "kd6d_teacher_select": [_L, _P, _P, _P, _F, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "kd6d_pose_candidates": [_L, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
     "kd6d_ssc_assign": [_L, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
-    "kd6d_focal_fwd": [_P, _P, _I, _F, _F, _P, _P],
+    "kd6d_focal_fwd": [_P, _P, _I, _F, _F, _P, _P, _P],
     "kd6d_focal_bwd": [_I, _P, _P, _I, _F, _F, _P, _P, _P],
     "kd6d_student_points": [_L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_float),
-                            _F, _F, _I, _P, _P, _P, _P, _P, _P],
+                            _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "kd6d_kd_mean": [_P, _P, _I, _P, _P, _P],
-    "kd6d_loss_backward": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I,
+    "kd6d_loss_backward": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _I, _I,
                            _P, _P, _P],
     "kd6d_dzi_crop": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P],
-    "kd6d_sumsq": [_P, _I64, _P, _P],
+    "kd6d_sumsq": [_P, _I64, _P, _P, _P],
     "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
     "kd6d_set_hyper": [_P, _D, _D, _D, _I64, _P],
     "kd6d_cast_f32_to_bf16": [_P, _P, _I64, _P],

@@ -38,7 +38,7 @@ def _pad8(c):
 # flat parameter store
 # ----------------------------------------------------------------------------------------
 class Entry:
-    __slots__ = ("name", "kind", "shape", "store_shape", "offset", "numel", "trainable", "region")
+    __slots__ = ("name", "kind", "shape", "store_shape", "offset", "numel", "trainable", "region", "det")
 
     def __init__(self, name, kind, shape, store_shape, trainable):
         self.name, self.kind, self.shape, self.store_shape = name, kind, tuple(shape), tuple(store_shape)
@@ -46,6 +46,7 @@ class Entry:
         self.trainable = trainable
         self.offset = -1
         self.region = None
+        self.det = False        # its gradient is summed in the fixed-point accumulator image (ParamStore.gacc)
 
 
 class ParamStore:
@@ -80,6 +81,8 @@ class ParamStore:
         self.params = torch.zeros(max(n_par, 8), dtype=torch.float32)
         self.bufs = torch.zeros(max(sizes["buf"], 8), dtype=torch.float32)
         self.grads = None
+        self.gacc = None
+        self._resolve_plans = {}
         self.shadow = None
         self.finalized = True
 
@@ -109,12 +112,67 @@ class ParamStore:
         self.bufs = self.bufs.to(device)
         if self.grads is not None:
             self.grads = self.grads.to(device)
+        if self.gacc is not None:
+            self.gacc = self.gacc.to(device)
+        self._resolve_plans = {}
         if self.shadow is not None:
             self.shadow = self.shadow.to(device)
 
     def ensure_grads(self):
         if self.grads is None:
             self.grads = torch.zeros(max(self.n_train, 8), dtype=torch.float32, device=self.params.device)
+        if self.gacc is None:
+            # Fixed-point accumulator image of the gradient bucket (csrc/kd6d_det.h, include/kd6d.h "reproducible
+            # reductions"): PLANAR, the lo words of all elements then the hi words.  Every gradient that is a sum over
+            # workgroups (per-layer weight gradients, bias gradients, GroupNorm gains / shifts, the head's scales) is
+            # added here with integer atomics -- bitwise reproducible -- and resolve_grads() turns the touched regions
+            # into fp32 gradients once per step, leaving them zero for the next one.
+            self.gacc = torch.zeros(2 * self.acc_stride, dtype=torch.int64, device=self.params.device)
+
+    @property
+    def acc_stride(self):
+        """Distance (int64 words) between the lo and the hi word of a gradient accumulator."""
+        return max(self.n_train, 8)
+
+    def acc(self, e):
+        """lo-plane view of the entry's gradient accumulators (pass with acc_stride to the kd6d entry points); marks
+        the entry for resolve_grads()."""
+        assert e.region == "train"
+        self.ensure_grads()
+        if not e.det:
+            e.det = True
+            self._resolve_plans = {}
+        b = self.base(e)
+        return self.gacc[b:b + e.numel]
+
+    def resolve_grads(self, lo=0, hi=None):
+        """grads[lo:hi] += value of the accumulators of every marked entry in that range; accumulators cleared.  One
+        launch (kd6d_grad_acc_resolve); the region table is built on first use -- outside any stream capture."""
+        hi = self.n_train if hi is None else hi
+        plan = self._resolve_plans.get((lo, hi))
+        if plan is None:
+            assert not torch.cuda.is_current_stream_capturing(), \
+                "ParamStore.resolve_grads: first use of a new set of accumulated gradients inside a graph capture " \
+                "(run one eager warm-up step first)"
+            regs = []
+            for e in self.order:
+                if e.region == "train" and e.det and lo <= self.base(e) < hi:
+                    b, n = self.base(e), e.numel
+                    if regs and regs[-1][0] + regs[-1][1] == b:
+                        regs[-1][1] += n
+                    else:
+                        regs.append([b, n])
+            desc, blk = [], 0
+            for b, n in regs:
+                desc += [b, n, blk]
+                blk += (n + 1023) // 1024
+            plan = (torch.tensor(desc or [0, 0, 0], dtype=torch.int64, device=self.params.device), len(regs), blk)
+            self._resolve_plans[(lo, hi)] = plan
+        desc, n_regions, blocks = plan
+        if n_regions == 0:
+            return
+        ops.check(ops.lib.kd6d_grad_acc_resolve(ops._ptr(desc), n_regions, blocks, ops._ptr(self.gacc), self.acc_stride,
+                                                ops._ptr(self.grads), ops._stream()), "kd6d_grad_acc_resolve")
 
     def ensure_shadow(self):
         if self.shadow is None:
@@ -211,16 +269,16 @@ class Conv:
             grp.add(g, x, dy, st.storage(self.w, "grads"), None if self.b is None else st.storage(self.b, "grads"),
                     flops=self.flops(g))
         elif (side := self.net.next_side_stream()) is None:
-            ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
-                             dbias=None if self.b is None else st.storage(self.b, "grads"))
+            ops.conv2d_wgrad(g, x, dy, st.acc(self.w), st.acc_stride, flops=self.flops(g),
+                             dbias=None if self.b is None else st.acc(self.b))
         else:
             # the weight gradient feeds nothing in the reverse sweep: fork it onto the side stream so it
             # overlaps the dgrad / normalisation chain (both under-fill 256 CUs at these layer sizes);
             # PoseNet.backward joins before the gradient exchange.  x and dy are per-layer buffers.
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ops.conv2d_wgrad(g, x, dy, st.storage(self.w, "grads"), flops=self.flops(g),
-                                 dbias=None if self.b is None else st.storage(self.b, "grads"),
+                ops.conv2d_wgrad(g, x, dy, st.acc(self.w), st.acc_stride, flops=self.flops(g),
+                                 dbias=None if self.b is None else st.acc(self.b),
                                  cu_budget=self.net.wgrad_cu_budget)
         if not need_dx:
             return None
@@ -259,6 +317,12 @@ class ConvBlock:
         """Replica rows of the backward reduction's accumulators (kd6d.h): from 64 workgroups up."""
         return 8 if rows >= (1 << 14) else 1
 
+    def scratch_floats(self, rows):
+        """fp32 slots of the block's slice of the per-step zeroed arena: {sum, sumsq} accumulators of the batch statistics,
+        saved mean / invstd, the backward's R replica rows of two accumulator sums, its barrier words."""
+        c, A, R = self.conv.cout_p, ops.ACC_FLOATS, self.bwd_replicas(rows)
+        return (2 * A + 2 + 2 * A * R) * c + ops.BARRIER_WORDS
+
     def __init__(self, net, name, cin, cout, k, stride=1):
         self.net, self.name = net, name
         self.conv = Conv(net, name + ".conv", cin, cout, k, stride, bias=False)
@@ -280,8 +344,10 @@ class ConvBlock:
         # the pre-BN tensor stays fp32 (also in bf16 mode): (x - mean) must not cancel bf16 rounding
         c = self.conv.cout_p
         geom = self.conv.geom(batch, levels)
-        s = net.scratch(self.name, (4 + 2 * self.bwd_replicas(geom.rows_out)) * c + ops.BARRIER_WORDS)   # + the backward's barrier words
-        ssum, ssq, mean, invstd = s[0:c], s[c:2 * c], s[2 * c:3 * c], s[3 * c:4 * c]
+        A = ops.ACC_FLOATS         # fp32 slots of one accumulator: the sums are kd6d_acc (reproducible reductions, kd6d.h)
+        s = net.scratch(self.name, self.scratch_floats(geom.rows_out))
+        ssum, ssq = s[0:A * c], s[A * c:2 * A * c]
+        mean, invstd = s[2 * A * c:(2 * A + 1) * c], s[(2 * A + 1) * c:(2 * A + 2) * c]
         if pending is not None or defer:
             raw = net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32)
             bn_in = z_in = None
@@ -294,9 +360,9 @@ class ConvBlock:
                 z_in = net.buf(prev.name + ".z", raw_prev.shape, net.dtype)     # written by this launch: what wgrad reads
                 x = raw_prev
             if defer:          # the consumer adds the replica rows
-                stats, reps = net.scratch(self.name + ".sums", ops.BN_REPLICAS * 2 * c), ops.BN_REPLICAS
+                stats, reps = net.scratch(self.name + ".sums", ops.BN_REPLICAS * 2 * c * A), ops.BN_REPLICAS
             else:              # bn_train_fwd / bn_pool_train_fwd below read plain {sum, sumsq}
-                stats, reps = s[0:2 * c], 1
+                stats, reps = s[0:2 * A * c], 1
             fused = defer or geom.rows_out <= self.FUSE_STATS_MAX_ROWS
             ops.conv2d_fwd_block(geom, x, self.conv.weight(), raw, stats=stats if fused else None, stats_replicas=reps,
                                  bn_in=bn_in, z_out=z_in, flops=self.conv.flops(geom))
@@ -323,7 +389,7 @@ class ConvBlock:
             fused = geom.rows_out <= self.FUSE_STATS_MAX_ROWS
             raw, g = self.conv.fwd(x, batch, levels, out_f32=True,
                                    out=net.buf(self.name + ".raw", (geom.rows_out, c), torch.float32),
-                                   stats=s[0:2 * c] if fused else None, stats_groups=0)
+                                   stats=s[0:2 * A * c] if fused else None, stats_groups=0)
             if not fused:
                 ops.colstats(raw, ssum, ssq)
         if pool:
@@ -343,11 +409,12 @@ class ConvBlock:
         _, x, raw, batch, levels, pooled = rec
         net, st = self.net, self.net.store
         c = self.conv.cout_p
-        R = self.bwd_replicas(raw.shape[0])
-        s = net.scratch(self.name, (4 + 2 * R) * c + ops.BARRIER_WORDS)
-        mean, invstd = s[2 * c:3 * c], s[3 * c:4 * c]
-        w1, w2 = s[4 * c:(4 + R) * c], s[(4 + R) * c:(4 + 2 * R) * c]
-        counter = s[(4 + 2 * R) * c:(4 + 2 * R) * c + ops.BARRIER_WORDS]      # zeroed with the arena at the start of the step
+        R, A = self.bwd_replicas(raw.shape[0]), ops.ACC_FLOATS
+        s = net.scratch(self.name, self.scratch_floats(raw.shape[0]))
+        mean, invstd = s[2 * A * c:(2 * A + 1) * c], s[(2 * A + 1) * c:(2 * A + 2) * c]
+        o = (2 * A + 2) * c
+        w1, w2 = s[o:o + A * R * c], s[o + A * R * c:o + 2 * A * R * c]
+        counter = s[o + 2 * A * R * c:o + 2 * A * R * c + ops.BARRIER_WORDS]      # zeroed with the arena at the start of the step
         draw = net.buf(self.name + ".draw", raw.shape, net.dtype)
         if pooled is not None:                  # dz is the gradient of the pooled output
             ops.bn_pool_train_bwd(raw, dz, draw, batch, pooled[0], pooled[1], mean, invstd, st.storage(self.bn.gamma),
@@ -370,7 +437,7 @@ class GroupNormReLU:
     def stats(self, batch, levels):
         """{sum, sumsq} per (level, image, group) in the per-step zeroed scratch arena; filled by the
         epilogue of the conv that produces this layer's input."""
-        return self.net.scratch(self.name + ".stats", len(levels) * batch * self.groups * 2)
+        return self.net.scratch(self.name + ".stats", len(levels) * batch * self.groups * 2 * ops.ACC_FLOATS)
 
     def fwd(self, x, batch, levels, out=None):
         net, st = self.net, self.net.store
@@ -393,13 +460,13 @@ class GroupNormReLU:
         net, st = self.net, self.net.store
         gsum = net.scratch(self.name + ".gsum", ops.gn_bwd_workspace_floats(len(levels), batch, self.groups))
         return (x, dz, dx, st.storage(self.gamma), st.storage(self.beta), self.stats(batch, levels), gsum,
-                st.storage(self.gamma, "grads"), st.storage(self.beta, "grads"))
+                st.acc(self.gamma), st.acc(self.beta))
 
     def bwd(self, x, dz, batch, levels, dx):
         hw = [h * w for (h, w) in levels]
         x, dz, dx, gamma, beta, stats, gsum, dgamma, dbeta = self.bwd_item(x, dz, batch, levels, dx)
         ops.gn_relu_bwd(x, dz, dx, hw, batch, self.groups, gamma, beta, stats, gsum, dgamma, dbeta,
-                        flags=ops.GN_WS_ZEROED)
+                        self.net.store.acc_stride, flags=ops.GN_WS_ZEROED)
         return dx
 
 
@@ -436,6 +503,7 @@ class PoseNet:
         self.cut_hook = None
         self.wgrad_group_flush = "head_end"     # or "fpn_end" (GraphedKDStep picks by launch mode)
         self.grad_hook = None           # called by backward() when the FPN + head gradients have been issued
+        self.resolve_hi = None          # backward() resolves the accumulated gradients of [0, resolve_hi) at its end (None: all)
         self.fuse_pool = True           # BN + act + maxpool as one kernel (training)
         # conv + normalisation + activation as one launch (kd6d_conv2d_fwd_norm: in-kernel barrier in the conv epilogue).
         # Measured on the step, interleaved runs on one box (profiles/README.md round 3): the frozen teacher's towers
@@ -858,7 +926,7 @@ class PoseNet:
                     draws[tname] = self.buf("%s.draw%d" % (tname, li), (r, oc))
                     items.append(gn.bwd_item(self.head_ctx[tname][0][li][1], dxs[tname], B, lv_all, draws[tname]))
                 ops.gn_relu_bwd_pair(items, [h * w for (h, w) in lv_all], B, self.cls_tower[li][1].groups,
-                                     flags=ops.GN_WS_ZEROED)
+                                     self.store.acc_stride, flags=ops.GN_WS_ZEROED)
                 if li > 0:
                     # the two data gradients as one launch; the weight gradients fork onto the side streams as usual
                     with ops.conv_pair(enabled=self.pair_towers == 1):
@@ -973,4 +1041,8 @@ class PoseNet:
         ops.mark("student.bwd.main.end")
         for side in (self.side_streams or ([self.side_stream] if self.side_stream is not None else [])):
             torch.cuda.current_stream().wait_stream(side)
+        # every accumulated gradient (per-layer weight / bias gradients, GroupNorm gains and shifts, the head's scales)
+        # -> fp32, accumulators cleared for the next step: one launch.  A caller that resolved the FPN + head part
+        # early (grad_hook, the overlapped exchange) sets resolve_hi to where that part begins.
+        self.store.resolve_grads(0, self.resolve_hi)
         return None

@@ -96,6 +96,7 @@ class GraphedKDStep:
         for side in [torch.cuda.current_stream()] + list(snet.side_streams or ([snet.side_stream] if snet.side_stream else [])):
             comm.wait_stream(side)
         with torch.cuda.stream(comm):
+            snet.store.resolve_grads(self._split, snet.store.n_train)      # accumulated FPN + head gradients -> fp32
             D.exchange_slice(snet.store, self._split, snet.store.n_train)
 
     def _student_step(self, pred_t):
@@ -110,11 +111,13 @@ class GraphedKDStep:
                 self.comm_stream = torch.cuda.Stream()
                 self._split = D.bucket_split(snet.store)
             snet.grad_hook = self._early_exchange
+            snet.resolve_hi = self._split
         try:
             losses = self.student.step_losses(self.images, self.tgt, pred_t, self._w)
         finally:
             snet.nhwc_in = None
             snet.grad_hook = None
+            snet.resolve_hi = None
         if overlap:        # the sweep has joined its side streams: the backbone's slice, behind the big one
             torch.cuda.current_stream().wait_stream(self.comm_stream)
             D.exchange_slice(snet.store, 0, self._split)

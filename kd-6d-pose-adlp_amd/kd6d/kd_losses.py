@@ -297,7 +297,7 @@ class KDLoss:
         ws = self._ws.get(key)
         if ws is None:
             n, bp = batch * self.cap, (batch + 3) // 4 * 4
-            ws = self._ws[key] = (torch.zeros(8 + bp + n * 64, dtype=torch.float32, device=device),
+            ws = self._ws[key] = (torch.zeros(8 + bp + n * 64 + 16, dtype=torch.float32, device=device),
                                   torch.zeros(3 * bp + 4 + 2 * n, dtype=torch.int32, device=device))
         return ws
 
@@ -327,7 +327,7 @@ class KDLoss:
         if prezeroed:
             wf, wi = self.workspaces(batch, dev)
         else:
-            wf = torch.zeros(8 + bp + n * 64, **f32)
+            wf = torch.zeros(8 + bp + n * 64 + 16, **f32)     # + the two loss sums' fixed-point workspaces
             wi = torch.zeros(3 * bp + 4 + 2 * n, **i32)
         pos_cnt = wi[0:batch]
         pos_row, pos_gt = wi[3 * bp + 4:3 * bp + 4 + n], wi[3 * bp + 4 + n:3 * bp + 4 + 2 * n]
@@ -360,13 +360,14 @@ class KDLoss:
         o = 8 + bp
         xs, g_reg, g_xs = (wf[o + k * n * 16:o + (k + 1) * n * 16].view(n, 8, 2) for k in range(3))
         alpha, g_alpha = (wf[o + n * 48 + k * n * 8:o + n * 48 + (k + 1) * n * 8].view(n, 8) for k in range(2))
-        check(lib.kd6d_focal_fwd(P(cls_s), P(labels), rows, self.gamma, self.alpha, P(losses[0:1]), st),
+        ws_cls, ws_reg = wf[o + n * 64:o + n * 64 + 8], wf[o + n * 64 + 8:o + n * 64 + 16]     # kd6d_scalar_ws each
+        check(lib.kd6d_focal_fwd(P(cls_s), P(labels), rows, self.gamma, self.alpha, P(losses[0:1]), P(ws_cls), st),
               "kd6d_focal_fwd")
         fw, fh = tgt.frame_wh
         check(lib.kd6d_student_points(ctypes.byref(lv), P(cls_s), P(reg_s), P(pos_cnt), P(pos_row), P(pos_gt),
                                       P(tgt.class_ids), P(tgt.kp3d), P(tgt.rot), P(tgt.trans), P(tgt.bbox_trans),
                                       P(self.diameters), self.kinv, fw, fh, cap, P(xs), P(alpha), P(g_reg),
-                                      P(losses[1:2]), P(s_start), st), "kd6d_student_points")
+                                      P(losses[1:2]), P(ws_reg), P(s_start), st), "kd6d_student_points")
         if teacher is not None:
             check(lib.kd6d_sinkhorn_div_fwd_bwd(P(xs), P(alpha), P(s_start), P(pos_cnt), P(teacher.t_kp_norm),
                                                 P(teacher.t_beta), P(teacher.t_start), P(teacher.t_cnt), batch, self.p,
@@ -378,8 +379,10 @@ class KDLoss:
                         rows=rows, batch=batch, xs=xs, alpha=alpha, seg_scale=seg_scale, losses=losses)
         return losses
 
-    def backward(self, weights, dtype, dcls, dreg, dseg_scale=None):
-        """weights: device fp32 tensor {d/d loss_cls, d/d loss_reg, d/d loss_kd}.  dreg must be zeroed."""
+    def backward(self, weights, dtype, dcls, dreg, dseg_scale=None, acc_stride=0):
+        """weights: device fp32 tensor {d/d loss_cls, d/d loss_reg, d/d loss_kd}.  dreg must be zeroed.  dseg_scale:
+        lo-plane view of the PLANAR gradient accumulators of the head's scales (int64, stride acc_stride), or None."""
+        assert dseg_scale is None or (dseg_scale.dtype == torch.int64 and acc_stride > 0)
         c = self.ctx
         P = ops._ptr
         st = ops._stream()
@@ -391,5 +394,5 @@ class KDLoss:
                                      P(c["pos_cnt"]), P(c["pos_row"]), P(c["pos_gt"]), P(tgt.class_ids),
                                      P(tgt.bbox_trans), P(c["g_reg"]), P(c["g_xs"]), P(c["g_alpha"]),
                                      P(c["n_valid"]), P(c["valid"]), P(weights), P(c["seg_scale"]),
-                                     P(dseg_scale), fw, fh, self.cap, int(self.detach), P(dcls), P(dreg), st),
+                                     P(dseg_scale), int(acc_stride), fw, fh, self.cap, int(self.detach), P(dcls), P(dreg), st),
               "kd6d_loss_backward")

@@ -312,7 +312,8 @@ class PoseModuleKD(nn.Module):
         dreg = net.buf("dreg", (rows, self.net.pose_pred.cout_p))
         if not dreg_zeroed:
             dreg.zero_()
-        self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.storage(net.scales, "grads"))
+        self.loss_evaluator.backward(weights, net.dtype, dcls, dreg, dseg_scale=st.acc(net.scales),
+                                     acc_stride=st.acc_stride)
         ops.mark("student.bwd.start")
         from ..libs import distributed as D
         own = not getattr(self, "_defer_allreduce", False)      # GraphedKDStep schedules the exchange itself
@@ -324,13 +325,16 @@ class PoseModuleKD(nn.Module):
                 for side in [torch.cuda.current_stream()] + list(net.side_streams or ([net.side_stream] if net.side_stream else [])):
                     comm.wait_stream(side)
                 with torch.cuda.stream(comm):
+                    st.resolve_grads(split, st.n_train)      # the accumulated FPN + head gradients -> fp32 first
                     D.exchange_slice(st, split, st.n_train)
             net.grad_hook = early
+            net.resolve_hi = split
         try:
             net.backward(dcls, dreg)
         finally:
             if split is not None:
                 net.grad_hook = None
+                net.resolve_hi = None
         ops.mark("student.bwd.end")
         if split is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)

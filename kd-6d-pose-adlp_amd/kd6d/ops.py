@@ -34,6 +34,40 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- reproducible reductions (include/kd6d.h): statistics and workspaces are kd6d_acc, 16 bytes each ----------
+ACC_FLOATS = 4                       # fp32 slots one accumulator takes in an fp32 arena
+ACC_ACT, ACC_GRAD = _lib.ACC_ACT, _lib.ACC_GRAD
+
+
+def acc_zeros(n, device):
+    """n zeroed accumulators as an fp32 tensor (the engine keeps them inside its per-step zeroed fp32 arena)."""
+    return torch.zeros(n * ACC_FLOATS, dtype=torch.float32, device=device)
+
+
+def acc_read(acc, n, kind, out=None, accumulate=False, clear=False):
+    """fp32 values of n interleaved accumulators (kd6d_acc_read): tests, debugging, stand-alone callers."""
+    assert acc.is_contiguous() and acc.numel() * acc.element_size() >= n * 16
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, dtype=torch.float32, device=acc.device)
+    check(lib.kd6d_acc_read(_ptr(acc), n, kind, _ptr(out), int(accumulate), int(clear), _stream()), "kd6d_acc_read")
+    return out
+
+
+def planar_acc(n, device):
+    """A stand-alone PLANAR gradient accumulator array for n elements: int64 (2 * n), lo plane then hi plane; pass
+    acc[:n] with stride n to conv2d_wgrad / gn_relu_bwd / loss_backward."""
+    return torch.zeros(2 * n, dtype=torch.int64, device=device)
+
+
+def planar_acc_value(acc):
+    """fp32 value of a stand-alone planar accumulator array made by planar_acc (torch arithmetic: test helper; the
+    engine resolves its gradient bucket with kd6d_grad_acc_resolve)."""
+    n = acc.numel() // 2
+    lo, hi = acc[:n].double(), acc[n:].double()
+    return (hi * 2.0 ** (47 - ACC_GRAD) + lo * 2.0 ** (-ACC_GRAD)).float()
+
+
 # ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----------
 _prof = None
 
@@ -140,9 +174,10 @@ def conv_norm_counter_words(geom, kind):
 
 
 def conv_norm_stats_floats(geom, kind, groups=0):
+    """fp32 slots of the fused launch's statistics accumulators."""
     if kind == NORM_BATCH:
-        return _lib.BN_FUSED_REPLICAS * 2 * geom.cout
-    return len(geom.levels_in) * geom.batch * groups * 2
+        return _lib.BN_FUSED_REPLICAS * 2 * geom.cout * ACC_FLOATS
+    return len(geom.levels_in) * geom.batch * groups * 2 * ACC_FLOATS
 
 
 def conv2d_fwd_norm(geom, x, w, y, kind, gamma, beta, stats, counters, act, raw_out=None, bias=None, groups=0, eps=1e-5,
@@ -153,7 +188,7 @@ def conv2d_fwd_norm(geom, x, w, y, kind, gamma, beta, stats, counters, act, raw_
     assert x.shape == (geom.rows_in, geom.cin) and w.dtype == x.dtype
     assert y.shape == (geom.rows_out, geom.cout) and y.dtype == x.dtype
     assert raw_out is None or (raw_out.shape == y.shape and raw_out.dtype == torch.float32)
-    assert stats.dtype == torch.float32 and stats.numel() >= conv_norm_stats_floats(geom, kind, groups)
+    assert stats.dtype == torch.float32 and stats.numel() >= conv_norm_stats_floats(geom, kind, groups)   # accumulators
     assert counters.numel() >= conv_norm_counter_words(geom, kind) and counters.element_size() == 4
     n = _lib.ConvNorm()
     n.kind, n.groups, n.act, n.eps, n.momentum = int(kind), int(groups), int(act), float(eps), float(momentum)
@@ -177,7 +212,7 @@ def conv2d_fwd_block(geom, x, w, y_raw, stats=None, stats_replicas=1, bn_in=None
     running_mean, running_var, save_mean, save_invstd) -- then x is the PREVIOUS block's fp32 conv output, normalised and
     activated while loaded, and z_out receives that activation (what this layer's weight gradient reads)."""
     assert y_raw.shape == (geom.rows_out, geom.cout) and y_raw.dtype == torch.float32
-    assert stats is None or (stats.dtype == torch.float32 and stats.numel() >= stats_replicas * 2 * geom.cout)
+    assert stats is None or (stats.dtype == torch.float32 and stats.numel() >= stats_replicas * 2 * geom.cout * ACC_FLOATS)
     bn = None
     if bn_in is not None:
         assert x.shape == (geom.rows_in, geom.cin) and x.dtype == torch.float32
@@ -185,7 +220,7 @@ def conv2d_fwd_block(geom, x, w, y_raw, stats=None, stats_replicas=1, bn_in=None
         bn = _lib.BnIn()
         bn.replicas, bn.act = int(bn_in["replicas"]), int(bn_in["act"])
         bn.eps, bn.momentum = float(bn_in.get("eps", 1e-5)), float(bn_in.get("momentum", 0.1))
-        assert bn_in["sums"].numel() >= bn.replicas * 2 * geom.cin
+        assert bn_in["sums"].numel() >= bn.replicas * 2 * geom.cin * ACC_FLOATS
         for name in ("sums", "gamma", "beta", "running_mean", "running_var", "save_mean", "save_invstd"):
             t = bn_in.get(name)
             assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32)
@@ -212,15 +247,27 @@ def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     return dx
 
 
-def conv2d_wgrad(geom, x, dy, dw, flops=0, dbias=None, cu_budget=0):
+def conv2d_wgrad(geom, x, dy, dw_acc, acc_stride, flops=0, dbias=None, cu_budget=0):
+    """dw_acc (and dbias): lo-plane views of PLANAR gradient accumulators (int64; the hi word of element i sits
+    acc_stride words behind its lo word: ParamStore.acc / planar_acc)."""
     assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
-    assert x.dtype == dy.dtype and dw.dtype == torch.float32
-    assert dw.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
+    assert x.dtype == dy.dtype and dw_acc.dtype == torch.int64 and acc_stride > 0
+    assert dw_acc.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
     with _Timed("conv_wgrad", flops, geom):
-        assert dbias is None or (dbias.dtype == torch.float32 and dbias.numel() >= geom.cout)
-        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), int(cu_budget),
-                                    _stream()), "kd6d_conv2d_wgrad")
-    return dw
+        assert dbias is None or (dbias.dtype == torch.int64 and dbias.numel() >= geom.cout)
+        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw_acc), _ptr(dbias),
+                                    int(acc_stride), int(cu_budget), _stream()), "kd6d_conv2d_wgrad")
+    return dw_acc
+
+
+def conv2d_wgrad_f32(geom, x, dy, with_bias=False, cu_budget=0):
+    """Stand-alone weight gradient -> fp32 tensors (dw, dbias | None): accumulators made, filled and converted here."""
+    nw = geom.cout * geom.ksize * geom.ksize * geom.cin
+    n = nw + (geom.cout if with_bias else 0)
+    acc = planar_acc(n, x.device)
+    conv2d_wgrad(geom, x, dy, acc[:nw], n, dbias=acc[nw:n] if with_bias else None, cu_budget=cu_budget)
+    v = planar_acc_value(acc)
+    return v[:nw], (v[nw:n] if with_bias else None)
 
 
 def set_option(name, value):
@@ -315,7 +362,9 @@ def pack_dgrad_weights(w_base, wt_base, desc_dev, n_layers, total_blocks):
 
 
 def colstats(x, sum_, sumsq=None):
+    """sum_ / sumsq: C accumulators each (acc_zeros(C) or slices of the zeroed arena), class ACC_ACT."""
     rows, c = x.shape
+    assert sum_.numel() >= c * ACC_FLOATS and (sumsq is None or sumsq.numel() >= c * ACC_FLOATS)
     check(lib.kd6d_colstats(dt_code(x.dtype), _ptr(x), rows, c, _ptr(sum_), _ptr(sumsq), _stream()),
           "kd6d_colstats")
 
@@ -340,10 +389,10 @@ BARRIER_WORDS = 32          # KD6D_BARRIER_WORDS: pre-zeroed 32-bit words of an 
 
 def bn_train_bwd(x, dz, dx, mean, invstd, gamma, beta, act, ws_sum_dy, ws_sum_dy_xhat, dgamma, dbeta, replicas=1,
                  counter=None):
-    """ws_sum_dy / ws_sum_dy_xhat: `replicas` rows of C floats each, pre-zeroed (kd6d.h).  counter: BARRIER_WORDS
+    """ws_sum_dy / ws_sum_dy_xhat: `replicas` rows of C accumulators each, pre-zeroed (kd6d.h).  counter: BARRIER_WORDS
     pre-zeroed 32-bit words -> the one-launch backward (in-kernel barrier) when the tensor fits; None -> reduce + apply."""
     rows, c = x.shape
-    assert ws_sum_dy.numel() >= replicas * c and ws_sum_dy_xhat.numel() >= replicas * c
+    assert ws_sum_dy.numel() >= replicas * c * ACC_FLOATS and ws_sum_dy_xhat.numel() >= replicas * c * ACC_FLOATS
     assert counter is None or counter.numel() >= BARRIER_WORDS
     check(lib.kd6d_bn_train_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), rows, c, _ptr(mean),
                                 _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy), _ptr(ws_sum_dy_xhat),
@@ -400,7 +449,7 @@ def bn_pool_train_bwd(x, dy, dx, batch, h, w, mean, invstd, gamma, beta, act, ws
     counter as in bn_train_bwd."""
     rows, c = x.shape
     assert rows == batch * h * w and tuple(dy.shape) == (batch * (h // 2) * (w // 2), c) and dx.shape == x.shape
-    assert ws_sum_dy.numel() >= replicas * c and ws_sum_dy_xhat.numel() >= replicas * c
+    assert ws_sum_dy.numel() >= replicas * c * ACC_FLOATS and ws_sum_dy_xhat.numel() >= replicas * c * ACC_FLOATS
     assert counter is None or counter.numel() >= BARRIER_WORDS
     check(lib.kd6d_bn_pool_train_bwd(dt_code(dy.dtype), _xf32(x, dy.dtype), _ptr(x), _ptr(dy), _ptr(dx), batch, h, w,
                                      c, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act, _ptr(ws_sum_dy),
@@ -417,7 +466,7 @@ def _hw_array(level_hw):
 def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats, flags=0):
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
-    assert stats.numel() >= len(level_hw) * batch * groups * 2
+    assert stats.numel() >= len(level_hw) * batch * groups * 2 * ACC_FLOATS
     check(lib.kd6d_gn_relu_fwd(dt_code(y.dtype), _xf32(x, y.dtype), _ptr(x), _ptr(y), _hw_array(level_hw), len(level_hw),
                                batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats), flags, _stream()),
           "kd6d_gn_relu_fwd")
@@ -425,23 +474,28 @@ def gn_relu_fwd(x, y, level_hw, batch, groups, gamma, beta, eps, stats, flags=0)
 
 
 def gn_bwd_workspace_floats(n_levels, batch, groups):
-    """Floats of kd6d_gn_relu_bwd's workspace: the group sums plus one barrier counter per (level, image)."""
-    return 2 * n_levels * batch * groups + n_levels * batch
+    """fp32 slots of kd6d_gn_relu_bwd's workspace: the group-sum accumulators plus one barrier counter per (level, image)."""
+    return 2 * n_levels * batch * groups * ACC_FLOATS + n_levels * batch
 
 
-def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta, eps=1e-5, flags=0):
+def gn_relu_bwd(x, dz, dx, level_hw, batch, groups, gamma, beta, stats, gsum_ws, dgamma, dbeta, acc_stride=0, eps=1e-5,
+                flags=0):
+    """dgamma / dbeta: lo-plane views of PLANAR gradient accumulators with stride acc_stride (ParamStore.acc /
+    planar_acc), or None."""
     rows, c = x.shape
     assert rows == batch * sum(level_hw)
     assert gsum_ws.numel() >= gn_bwd_workspace_floats(len(level_hw), batch, groups), "gsum_ws too small (kd6d.h)"
+    assert all(t is None or t.dtype == torch.int64 for t in (dgamma, dbeta))
     check(lib.kd6d_gn_relu_bwd(dt_code(dz.dtype), _xf32(x, dz.dtype), _ptr(x), _ptr(dz), _ptr(dx), _hw_array(level_hw),
                                len(level_hw), batch, c, groups, _ptr(gamma), _ptr(beta), eps, _ptr(stats),
-                               _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), flags, _stream()), "kd6d_gn_relu_bwd")
+                               _ptr(gsum_ws), _ptr(dgamma), _ptr(dbeta), int(acc_stride), flags, _stream()),
+          "kd6d_gn_relu_bwd")
     return dx
 
 
-def gn_relu_bwd_pair(items, level_hw, batch, groups, eps=1e-5, flags=0):
+def gn_relu_bwd_pair(items, level_hw, batch, groups, acc_stride, eps=1e-5, flags=0):
     """Two gn_relu_bwd of identical geometry as one launch (kd6d_gn_relu_bwd_pair).  items: two tuples
-    (x, dz, dx, gamma, beta, stats, gsum_ws, dgamma, dbeta)."""
+    (x, dz, dx, gamma, beta, stats, gsum_ws, dgamma, dbeta); dgamma / dbeta as in gn_relu_bwd."""
     assert len(items) == 2
     packed = []
     for (x, dz, dx, gamma, beta, stats, gsum_ws, dgamma, dbeta) in items:
@@ -457,7 +511,7 @@ def gn_relu_bwd_pair(items, level_hw, batch, groups, eps=1e-5, flags=0):
     x0, dz0 = items[0][0], items[0][1]
     check(lib.kd6d_gn_relu_bwd_pair(dt_code(dz0.dtype), _xf32(x0, dz0.dtype), ctypes.byref(packed[0]),
                                     ctypes.byref(packed[1]), _hw_array(level_hw), len(level_hw), batch, x0.shape[1],
-                                    groups, eps, flags, _stream()), "kd6d_gn_relu_bwd_pair")
+                                    groups, eps, int(acc_stride), flags, _stream()), "kd6d_gn_relu_bwd_pair")
 
 
 def maxpool2_fwd(x, y, b, h, w):

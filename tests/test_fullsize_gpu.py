@@ -102,10 +102,8 @@ def test_conv_layer_at_benchmark_shape(gpu_device, layer):
     dys = [round_to(torch.randn(B, cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
     dyp = pack_levels(dys, dtype).to(dev)
     dx = ops.conv2d_dgrad(geom, dyp, w_to_dgrad(w, dtype).to(dev))
-    dw = torch.zeros(cout, k, k, cin, dtype=torch.float32, device=dev)
-    dw_half = torch.zeros_like(dw)
-    ops.conv2d_wgrad(geom, xp, dyp, dw)
-    ops.conv2d_wgrad(geom, xp, dyp, dw_half, cu_budget=128)      # the pipelined step sizes forked launches for CUs / 2
+    dw = ops.conv2d_wgrad_f32(geom, xp, dyp)[0].view(cout, k, k, cin)
+    dw_half = ops.conv2d_wgrad_f32(geom, xp, dyp, cu_budget=128)[0].view(cout, k, k, cin)   # the pipelined step sizes forked launches for CUs / 2
     torch.cuda.synchronize()
     ref_w = torch.zeros(cout, cin, k, k)
     for (h, w_), x, dy, gl in zip(levels, xs, dys, unpack_levels(dx.cpu(), B, levels)):
