@@ -123,9 +123,8 @@ def _grads(student):
     return {k: p.grad.detach().float().cpu().clone() for k, p in student.named_parameters() if p.grad is not None}
 
 
-def _grad_report(student, ref_grads, clip, gn_ref, exclude=()):
-    """exclude: tensors left out of the per-tensor maxima (they still count in the weighted mean, the total and the
-    cosine); the caller passes the tensors whose gradient is not reproducible between two runs of the HIP path itself."""
+def _grad_report(student, ref_grads, clip, gn_ref):
+    """Every gradient tensor of the student against the oracle's: no tensor is set aside."""
     got = _grads(student)
     dev_norm, dev_elem, num, den = {}, {}, 0.0, 0.0
     big = {}
@@ -135,8 +134,6 @@ def _grad_report(student, ref_grads, clip, gn_ref, exclude=()):
         dn = abs(float(got[k].norm()) - rn) / max(rn, 1e-6 * gn_ref)
         num += dn * rn ** 2
         den += rn ** 2
-        if k in exclude:
-            continue
         dev_norm[k] = dn
         dev_elem[k] = float((got[k] - r).norm()) / max(rn, 1e-6 * gn_ref)
         if g.numel() >= 1024:
@@ -168,11 +165,8 @@ TOL = {
     # +-lr per element with 2.5-3 % of the signs in disagreement): cls <= 2e-4, reg 2e-4 ... 1.5e-3 on config 2 and 1.4e-3 /
     # 1.9e-3 / 2.3e-3 / 2.8e-3 on config 4 in four runs of the same tree -- run-to-run noise of the HIP path, not drift: the
     # bound for it is 6e-3
-    "bf16": dict(loss=4e-3, kd=4e-2, gn=1e-3, worst=0.2, worst1k=0.1, wmean=6e-4, cos=3e-4, loss2=6e-3, sign=0.955),
+    "bf16": dict(loss=4e-3, kd=4e-2, gn=1e-3, worst=1.3, worst1k=0.3, wmean=6e-4, cos=3e-4, loss2=6e-3, sign=0.955),
 }
-# three runs of the HIP path on the same inputs (two twins + the step under test): a per-tensor gradient norm that moves
-# by more than this between any two of them is noise
-NOISY = 0.02
 # a bf16 step against the fp32 oracle (format error included): the round-2 bounds, for the record
 TOL_BF16_VS_FP32 = dict(loss=3e-3, kd=4e-2, gn=1e-3, worst=1.3, worst1k=0.3, wmean=2e-3, cos=1e-3)
 
@@ -258,76 +252,46 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
     if mixed:
         assert len({int(t["class_ids"][0]) for t in cpu_batches[0][1]}) == 13
 
-    noisy = {}
-    if precision == "bf16":
-        # Reproducibility of the HIP path itself: the same first step from identical state in a second set of objects.
-        # fp32 atomics retire in a different order from run to run (1e-7 relative), a bf16 store turns that into
-        # occasional 2^-9 flips, and the small BatchNorm tensors of the first layers amplify those (a 1e-4 relative
-        # perturbation of the input image moves them by 10-30 % in the ORACLE, profiles/r03_bf16_sensitivity.md).  A
-        # tensor whose gradient norm differs by more than NOISY between two runs of the same binary on the same inputs
-        # cannot be held to a tighter bound against anything: it is reported, not bounded per tensor (it still counts
-        # in the global norm, the weighted mean, the cosine and the update-sign agreement).
-        twins = []
-        for _ in range(2):
-            t_ = build("darknet53", precision, 2, dev, BIAS).eval()
-            s_ = build(arch, precision, 1, dev).train()
-            s_._debug_keys = student._debug_keys
-            o_ = FusedClipAdamW(s_, lr=1e-3, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
+    # Reproducibility of the HIP path itself (round 4): the same first step from identical state in a second set of
+    # objects, the SAME launch mode.  Every cross-workgroup sum of the library is an integer sum of fixed-point images
+    # (csrc/kd6d_det.h), so the two executions must agree BIT FOR BIT -- losses, gradient norm, every one of the 150
+    # gradient tensors -- in fp32 and in bf16 (rounds 2-3: 15-30 tensors moved by 2-21 % from run to run in bf16, and a
+    # twin-run exclusion list stood here).  Reference behaviour matched: train_kd.py:137-140, one deterministic backward.
+    def first_step(t_, s_, o_):
+        if group == 1:
             g_ = GraphedKDStep(t_, s_, o_, (0.1, 1.0, 5.0), pipeline=True)
-            assert g_(*batches[0]) is None
-            g_(*batches[1])
-            torch.cuda.synchronize()
-            twins.append(_grads(s_))
-            del g_, o_, s_, t_
-        for k, a in twins[0].items():
-            na, nb = float(a.norm()), float(twins[1][k].norm())
-            d = abs(na - nb) / max(na, nb, 1e-30)
-            if d > NOISY:
-                noisy[k] = d
-        twin0, twin1 = twins
-        del twins
-        torch.cuda.empty_cache()
+            assert g_(*batches[0]) is None                      # priming call: teacher(0)
+            out = g_(*batches[1])                               # teacher(1) beside the student step on batch 0 (captures)
+        else:
+            g_ = GroupedTeacherKDStep(t_, s_, o_, (0.1, 1.0, 5.0), group=group)
+            for i in range(2 * group):                          # two periods fill the pipeline: batches 0, 1, 0, 1, ...
+                assert g_(*batches[i % 2]) is None
+            out = g_(*batches[0])                               # the student step on batch 0 (captures)
+        torch.cuda.synchronize()
+        return g_, out
+
+    t2 = build("darknet53", precision, 2, dev, BIAS).eval()
+    s2 = build(arch, precision, 1, dev).train()
+    s2._debug_keys = student._debug_keys
+    o2 = FusedClipAdamW(s2, lr=1e-3, weight_decay=1e-4, eps=1e-8, max_norm=1.0)
+    g2, ld_twin = first_step(t2, s2, o2)
+    twin = dict(grads=_grads(s2), losses={k: float(v) for k, v in ld_twin.items()}, gn=float(o2.grad_norm()))
+    del g2, o2, s2, t2, ld_twin
+    torch.cuda.empty_cache()
 
     p0 = student.net.store.params.detach().cpu().clone()
-    if group == 1:
-        gs = GraphedKDStep(teacher, student, opt, (0.1, 1.0, 5.0), pipeline=True)
-        assert gs(*batches[0]) is None                      # priming call: teacher(0)
-        ld = gs(*batches[1])                                # teacher(1) beside the student step on batch 0 (captures)
-    else:
-        gs = GroupedTeacherKDStep(teacher, student, opt, (0.1, 1.0, 5.0), group=group)
-        for i in range(2 * group):                          # two periods fill the pipeline: batches 0, 1, 0, 1, ...
-            assert gs(*batches[i % 2]) is None
-        ld = gs(*batches[0])                                # the student step on batch 0 (captures)
-    torch.cuda.synchronize()
+    gs, ld = first_step(teacher, student, opt)
     got1 = {k: float(v) for k, v in ld.items()}
     gn1 = float(opt.grad_norm())
+    not_reproducible = {k: float((g - twin["grads"][k]).abs().max()) for k, g in _grads(student).items()
+                        if not torch.equal(g, twin["grads"][k])}
     # oracle, step 1 (and 2): fp32 mode vs the fp32 oracle, bf16 mode vs its bf16-storage emulation (see TOL)
     emulate = precision == "bf16"
     res1, ref_grads, res2 = _oracle_steps(arch, mixed, full, emulate, cpu_batches, choose, two_steps=not full)
     clip = min(1.0, 1.0 / (res1["grad_norm"] + 1e-6))
-    if noisy is not None and precision == "bf16":
-        # the step under test is a third execution of the same arithmetic (in the grouped mode the teacher's layers even
-        # tile 48 images instead of 16, so its cells agree with the twins' to rounding, not bitwise): a tensor on which it
-        # and a twin disagree by more than NOISY is not reproducible either -- two twins that happen to agree with each
-        # other do not make it so (seen once in ~10 runs of the full-frame case: one 64-element BatchNorm gain at 0.21
-        # against the bound of 0.2, not flagged by the twins of that run) -- same treatment, same energy bound below
-        sub = _grads(student)
-        pairdev = {}
-        for k, a in twin0.items():
-            n3 = [float(a.norm()), float(twin1[k].norm()), float(sub[k].norm())]
-            pairdev[k] = (max(n3) - min(n3)) / max(max(n3), 1e-30)        # the largest of the three pairwise deviations
-            if pairdev[k] > NOISY:
-                noisy[k] = pairdev[k]
-    rep = _grad_report(student, ref_grads, clip, res1["grad_norm"], exclude=noisy)
-    rep["not_reproducible"] = noisy
-    if precision == "bf16":          # how reproducible the tensor that sets `worst_norm` was among the three executions
-        rep["worst_norm_run_to_run"] = pairdev.get(rep["worst_norm_name"])
-    # what is set aside this way must be a negligible part of the update: < 0.1 % of the squared gradient norm (measured:
-    # 20-27 of 150 tensors at NOISY = 2 % over three executions, nearly all BatchNorm gains / biases and narrow convolutions
-    # of the student's backbone, run-to-run deviation 2-21 %; FPN and head, where 99.9 % of the gradient's norm is,
-    # reproduce.  The tensors that remain deviate from the emulation by 0.02-0.08 at most -- `worst_norm_run_to_run` records
-    # how reproducible the one that sets the maximum was)
-    assert sum(float(ref_grads[k].norm()) ** 2 for k in noisy) <= 1e-3 * res1["grad_norm"] ** 2, noisy
+    rep = _grad_report(student, ref_grads, clip, res1["grad_norm"])
+    rep["not_reproducible"] = not_reproducible
+    rep["twin_losses_equal"] = twin["losses"] == got1 and twin["gn"] == gn1
     if emulate and not full:
         # for the record: the same bf16 step against the plain fp32 oracle (number-format error included)
         f1, fgrads, _ = _oracle_steps(arch, mixed, full, False, cpu_batches, choose, two_steps=True)
@@ -370,6 +334,8 @@ def _pipelined_graph_vs_oracle(gpu_device, precision, arch, mixed, full, group=1
     print("[fullsize %s %s] %s" % (arch, precision, json.dumps(rep, default=str)))
 
     assert rep["barrier_timeouts"] == 0
+    assert rep["not_reproducible"] == {}, "two executions of the same step differ: %s" % rep["not_reproducible"]
+    assert rep["twin_losses_equal"], (twin["losses"], got1, twin["gn"], gn1)
     assert res1["loss_kd"] > 0, "the KD term must be active"
     assert rep["d_loss_cls"] <= tol["loss"] and rep["d_loss_reg"] <= tol["loss"], rep
     assert rep["d_loss_kd"] <= tol["kd"], rep

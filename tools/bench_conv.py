@@ -92,14 +92,15 @@ def main():
         dy = (torch.randn(geom.rows_out, cout, generator=g) * 0.5).to(torch.bfloat16).to(dev)
         y = torch.empty(geom.rows_out, cout, dtype=torch.bfloat16, device=dev)
         dx = torch.empty(geom.rows_in, cin, dtype=torch.bfloat16, device=dev)
-        dw = torch.zeros(cout * k * k * cin, dtype=torch.float32, device=dev)
+        nw = cout * k * k * cin
+        dw = ops.planar_acc(nw, dev)          # planar gradient accumulators (kd6d.h)
         flop = 2.0 * geom.rows_out * cout * k * k * cin
         for kind in kinds:
             if name.startswith(("t.", "t640.")) and kind != "fwd":
                 continue
             if kind == "fwd" and a.stats >= 0:
                 yf = torch.empty(geom.rows_out, cout, dtype=torch.float32, device=dev)
-                st = torch.zeros(max(2 * cout, len(levels) * a.batch * max(a.stats, 1) * 2), device=dev)
+                st = ops.acc_zeros(max(2 * cout, len(levels) * a.batch * max(a.stats, 1) * 2), dev)
                 us0 = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=yf, out_f32=True), a.iters)
                 us = timeit(lambda: ops.conv2d_fwd(geom, x, w, out=yf, out_f32=True, stats=st, stats_groups=a.stats), a.iters)
                 name = name + " (f32 out %.1f us; +stats)" % us0
@@ -108,7 +109,7 @@ def main():
             elif kind == "dgrad":
                 us = timeit(lambda: ops.conv2d_dgrad(geom, dy, w, dx=dx), a.iters)
             else:
-                us = timeit(lambda: ops.conv2d_wgrad(geom, x, dy, dw), a.iters)
+                us = timeit(lambda: ops.conv2d_wgrad(geom, x, dy, dw[:nw], nw), a.iters)
             print("| %s | %s | %d | %d | %d | %.2f | %.1f | %.0f |" % (name, kind, geom.rows_out, cout, k * k * cin,
                                                                       flop / 1e9, us, flop / max(us, 1e-9) / 1e6))
 

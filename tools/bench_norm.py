@@ -28,6 +28,15 @@ BN_LAYERS = [("u1", 256 * 256, 8), ("u2", 128 * 128, 16), ("s3.1x1", 64 * 64, 8)
 GN_LEVELS = [32 * 32, 16 * 16, 8 * 8, 4 * 4]
 
 
+def bn_scratch(c, R, dev):
+    """{sum, sumsq} accumulators, mean, invstd, R replica rows of the backward's two accumulator sums (engine layout)."""
+    A = ops.ACC_FLOATS
+    s = torch.zeros((2 * A + 2 + 2 * A * R) * c, device=dev)
+    o = (2 * A + 2) * c
+    return dict(sum=s[0:A * c], sumsq=s[A * c:2 * A * c], mean=s[2 * A * c:(2 * A + 1) * c],
+                invstd=s[(2 * A + 1) * c:o], w1=s[o:o + A * R * c], w2=s[o + A * R * c:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
@@ -47,28 +56,28 @@ def main():
         y = torch.empty(rows, c, dtype=bf, device=dev)
         dx = torch.empty(rows, c, dtype=bf, device=dev)
         R = 8 if rows >= (1 << 14) else 1          # as kd6d/engine.py ConvBlock.bwd_replicas
-        s = torch.zeros((4 + 2 * R) * c, device=dev)
+        q = bn_scratch(c, R, dev)
         gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
         rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
         dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-        ops.colstats(x, s[0:c], s[c:2 * c])
+        ops.colstats(x, q['sum'], q['sumsq'])
         mb_x, mb_a = rows * c * 4 / 1e6, rows * c * 2 / 1e6
-        row(name, "colstats", rows, c, mb_x, timeit_graph(lambda: ops.colstats(x, s[0:c], s[c:2 * c]), a.iters))
+        row(name, "colstats", rows, c, mb_x, timeit_graph(lambda: ops.colstats(x, q['sum'], q['sumsq']), a.iters))
         row(name, "bn_apply_fwd", rows, c, mb_x + mb_a, timeit_graph(
-            lambda: ops.bn_train_fwd(x, y, s[0:c], s[c:2 * c], gamma, beta, 1e-5, 0.1, rm, rv, s[2 * c:3 * c],
-                                     s[3 * c:4 * c], 1), a.iters))
+            lambda: ops.bn_train_fwd(x, y, q['sum'], q['sumsq'], gamma, beta, 1e-5, 0.1, rm, rv, q['mean'],
+                                     q['invstd'], 1), a.iters))
         c_ = ops.lib
 
         def reduce_only():
             ops.check(c_.kd6d_bn_train_bwd_reduce(ops.dt_code(bf), 1, ops._ptr(x), ops._ptr(dz), rows, c,
-                                                  ops._ptr(s[2 * c:3 * c]), ops._ptr(s[3 * c:4 * c]), ops._ptr(gamma),
-                                                  ops._ptr(beta), 1, ops._ptr(s[4 * c:]), ops._ptr(s[(4 + R) * c:]),
+                                                  ops._ptr(q['mean']), ops._ptr(q['invstd']), ops._ptr(gamma),
+                                                  ops._ptr(beta), 1, ops._ptr(q['w1']), ops._ptr(q['w2']),
                                                   R, ops._stream()), "reduce")
 
         def apply_only():
             ops.check(c_.kd6d_bn_train_bwd_apply(ops.dt_code(bf), 1, ops._ptr(x), ops._ptr(dz), ops._ptr(dx), rows, c,
-                                                 ops._ptr(s[2 * c:3 * c]), ops._ptr(s[3 * c:4 * c]), ops._ptr(gamma),
-                                                 ops._ptr(beta), 1, ops._ptr(s[4 * c:]), ops._ptr(s[(4 + R) * c:]),
+                                                 ops._ptr(q['mean']), ops._ptr(q['invstd']), ops._ptr(gamma),
+                                                 ops._ptr(beta), 1, ops._ptr(q['w1']), ops._ptr(q['w2']),
                                                  ops._ptr(dg), ops._ptr(db), R, ops._stream()), "apply")
 
         row(name, "bn_bwd_reduce", rows, c, mb_x + mb_a, timeit_graph(reduce_only, a.iters))
@@ -77,13 +86,13 @@ def main():
 
         def onepass():      # the counter (and the sums) are NOT re-zeroed between the timed launches: the barrier is
             ctr.zero_()     # passed at once after the first -- so zero it inside the timed region (one small memset)
-            ops.bn_train_bwd(x, dz, dx, s[2 * c:3 * c], s[3 * c:4 * c], gamma, beta, 1, s[4 * c:(4 + R) * c],
-                             s[(4 + R) * c:], dg, db, replicas=R, counter=ctr)
+            ops.bn_train_bwd(x, dz, dx, q['mean'], q['invstd'], gamma, beta, 1, q['w1'],
+                             q['w2'], dg, db, replicas=R, counter=ctr)
 
         def pair():
             ctr.zero_()
-            ops.bn_train_bwd(x, dz, dx, s[2 * c:3 * c], s[3 * c:4 * c], gamma, beta, 1, s[4 * c:(4 + R) * c],
-                             s[(4 + R) * c:], dg, db, replicas=R, counter=None)
+            ops.bn_train_bwd(x, dz, dx, q['mean'], q['invstd'], gamma, beta, 1, q['w1'],
+                             q['w2'], dg, db, replicas=R, counter=None)
 
         row(name, "bn_bwd pair + memset", rows, c, 2 * mb_x + 3 * mb_a, timeit_graph(pair, a.iters))
         row(name, "bn_bwd one launch + memset", rows, c, mb_x + 2 * mb_a, timeit_graph(onepass, a.iters))
@@ -98,16 +107,16 @@ def main():
         dyp = torch.randn(rows // 4, c, device=dev).to(bf)
         dx = torch.empty(rows, c, dtype=bf, device=dev)
         R = 8 if rows >= (1 << 14) else 1
-        s = torch.zeros((4 + 2 * R) * c, device=dev)
+        q = bn_scratch(c, R, dev)
         gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
         rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
         dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-        ops.colstats(x, s[0:c], s[c:2 * c])
-        mean, invstd, w1, w2 = s[2 * c:3 * c], s[3 * c:4 * c], s[4 * c:(4 + R) * c], s[(4 + R) * c:]
+        ops.colstats(x, q['sum'], q['sumsq'])
+        mean, invstd, w1, w2 = q['mean'], q['invstd'], q['w1'], q['w2']
         mb_x, mb_a = rows * c * 4 / 1e6, rows * c * 2 / 1e6
 
         def fwd_sep():
-            ops.bn_train_fwd(x, z, s[0:c], s[c:2 * c], gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
+            ops.bn_train_fwd(x, z, q['sum'], q['sumsq'], gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, 1)
             ops.maxpool2_fwd(z, yp, B, side, side)
 
         def bwd_sep():
@@ -116,7 +125,7 @@ def main():
 
         row(name, "bn_apply + maxpool (2 launches)", rows, c, mb_x + 2.25 * mb_a, timeit_graph(fwd_sep, a.iters))
         row(name, "bn_pool_fwd (fused)", rows, c, mb_x + 0.25 * mb_a, timeit_graph(
-            lambda: ops.bn_pool_train_fwd(x, yp, B, side, side, s[0:c], s[c:2 * c], gamma, beta, 1e-5, 0.1, rm, rv,
+            lambda: ops.bn_pool_train_fwd(x, yp, B, side, side, q['sum'], q['sumsq'], gamma, beta, 1e-5, 0.1, rm, rv,
                                           mean, invstd, 1), a.iters))
         row(name, "maxpool_bwd + bn_bwd (3 launches)", rows, c, 2 * mb_x + 5.25 * mb_a, timeit_graph(bwd_sep, a.iters))
         row(name, "bn_pool_bwd (fused, 2 launches)", rows, c, 2 * mb_x + 1.5 * mb_a, timeit_graph(
@@ -130,15 +139,16 @@ def main():
     y = torch.empty(rows, c, dtype=bf, device=dev)
     dx = torch.empty(rows, c, dtype=bf, device=dev)
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
-    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-    stats = torch.zeros(len(GN_LEVELS) * B * groups * 2, device=dev)
+    ga = ops.planar_acc(2 * c, dev)
+    dg, db = ga[0:c], ga[c:2 * c]
+    stats = ops.acc_zeros(len(GN_LEVELS) * B * groups * 2, dev)
     gsum = torch.zeros(ops.gn_bwd_workspace_floats(len(GN_LEVELS), B, groups), device=dev)
     ops.gn_relu_fwd(x, y, GN_LEVELS, B, groups, gamma, beta, 1e-5, stats)
     mb_x, mb_a = rows * c * 4 / 1e6, rows * c * 2 / 1e6
     row("head", "gn_fwd (stats ready)", rows, c, mb_x + mb_a, timeit_graph(
         lambda: ops.gn_relu_fwd(x, y, GN_LEVELS, B, groups, gamma, beta, 1e-5, stats, flags=ops.GN_STATS_READY), a.iters))
     row("head", "gn_bwd (reduce + apply)", rows, c, 2 * mb_x + 3 * mb_a, timeit_graph(
-        lambda: ops.gn_relu_bwd(x, dz, dx, GN_LEVELS, B, groups, gamma, beta, stats, gsum, dg, db), a.iters))
+        lambda: ops.gn_relu_bwd(x, dz, dx, GN_LEVELS, B, groups, gamma, beta, stats, gsum, dg, db, 2 * c), a.iters))
 
 
 if __name__ == "__main__":

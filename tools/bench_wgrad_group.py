@@ -38,9 +38,12 @@ def main():
         layers.append((geom, x, dy, dw, db))
     flop = sum(2.0 * ge.rows_out * ge.cout * 9 * C for ge, *_ in layers)
 
+    accs = [ops.planar_acc(dw.numel() + db.numel(), dev) for _, _, _, dw, db in layers]      # kd6d.h: planar accumulators
+
     def per_layer(budget):
-        for ge, x, dy, dw, db in layers:
-            ops.conv2d_wgrad(ge, x, dy, dw, dbias=db, cu_budget=budget)
+        for (ge, x, dy, dw, db), acc in zip(layers, accs):
+            n = dw.numel() + db.numel()
+            ops.conv2d_wgrad(ge, x, dy, acc[:dw.numel()], n, dbias=acc[dw.numel():n], cu_budget=budget)
 
     for budget in (0, 128):
         us = timeit_graph(lambda: per_layer(budget), a.iters)
