@@ -75,6 +75,9 @@ def get_argparser():
     p.add_argument("--exchange", type=str, default="between", choices=["between", "overlap"],
                    help="data-parallel gradient exchange: one all-reduce between the step's two graphs, or two slices inside "
                         "the step (FPN + head beside the backbone sweep; kd6d/libs/distributed.py EXCHANGE_MODE)")
+    p.add_argument("--rccl_single_rank", action="store_true",
+                   help="one process, one GPU, but the whole data-parallel path: a one-rank process group, the kd6d "
+                        "communicator, the parameter broadcast and every step's all-reduce (rehearsal on a one-GPU box)")
     p.add_argument("--mixed_classes", type=str2bool, nargs="?", const=True, default=None,
                    help="synthetic batches mix the 13 LINEMOD classes (default: DATASETS.MIXED_CLASSES of the yaml)")
     return p
@@ -104,7 +107,8 @@ def _runtime(args, config_file, weight_file):
     return dict(LOCAL_RANK=args.local_rank, CONFIG_FILE=config_file, NUM_WORKERS=args.num_workers,
                 WEIGHT_FILE=weight_file, RUNNING_DEVICE=args.running_device, PRECISION=args.precision,
                 TEACHER_PNP_GATE=bool(args.teacher_pnp_gate),
-                TWO_LAUNCH_NORM_BWD=bool(args.two_launch_norm_bwd), EXCHANGE=args.exchange)
+                TWO_LAUNCH_NORM_BWD=bool(args.two_launch_norm_bwd), EXCHANGE=args.exchange,
+                RCCL_SINGLE_RANK=bool(getattr(args, "rccl_single_rank", False)))
 
 
 def build_cfgs(args):

@@ -634,6 +634,20 @@ class PoseNet:
             bn.fold = None
         self._weights_dirty = True
 
+    def refresh_derived_in_place(self, need_dgrad=False):
+        """The master weights / buffers changed BEHIND recorded hipGraphs (a parameter broadcast after the step was
+        captured: train_kd.py's graphs-first start of a data-parallel run): recompute everything the recorded kernels read
+        that is derived from them INTO THE BUFFERS THEY WERE RECORDED WITH -- the bf16 shadow, the dgrad packing and the
+        eval-mode BatchNorm folds.  (invalidate() would free the fold tensors whose addresses the graphs hold.)"""
+        st = self.store
+        for _, bn in self.bns:
+            if bn.fold is not None:
+                scale = st.storage(bn.gamma) * torch.rsqrt(st.storage(bn.rv) + 1e-5)
+                bn.fold[0].copy_(scale)
+                bn.fold[1].copy_(st.storage(bn.beta) - st.storage(bn.rm) * scale)
+        self._weights_dirty = True
+        self.prepare_weights(need_dgrad=need_dgrad and self.wt is not None)
+
     def to(self, device):
         self.store.to(device)
         self._bufs.clear()

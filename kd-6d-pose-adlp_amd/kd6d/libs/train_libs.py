@@ -195,3 +195,46 @@ def dataset_meshes(loader):
     dset = loader.loader.dataset
     dset = dset.datasets[0] if hasattr(dset, "datasets") else dset
     return [m.vertices for m in dset.meshes]
+
+
+def start_exchange_after_graphs(gstep, model_t, model, first_batch, log=print):
+    """Data-parallel run in the grouped launch mode (train_kd.py --launch pipeline --teacher_group > 1, `between` exchange):
+    the step's hipGraphs are recorded BEFORE the process's first RCCL communicator exists (graphs instantiated after
+    ncclCommInitRank replay ~18 % slower in that mode).  Order, every rank alike:
+      1. gstep.prepare(first batch)      every graph recorded, pipeline left empty, training state untouched
+      2. barrier, init_exchange()        the ranks agree, then the kd6d communicator (kd6d_comm_init is collective)
+      3. broadcast rank 0's parameters and buffers of teacher and student (what build_model* deferred:
+         libs/train_libs.py:123-130 of the reference, the DDP constructor's broadcast)
+      4. refresh IN PLACE what the recorded kernels read of them: bf16 shadows, the student's dgrad packing and the
+         teacher's eval-mode BatchNorm folds (PoseNet.refresh_derived_in_place; the teacher's segments were recorded on
+         its pre-broadcast folds and shadow -- a rank whose initial teacher differed from rank 0's would otherwise distil
+         from a different teacher)
+    The first batch is then fed as usual by the caller.  Returns the exchange route string."""
+    gstep.prepare(first_batch[0], first_batch[1])
+    D.synchronize()
+    route = D.init_exchange()
+    log("gradient exchange: " + route)
+    for m in (model_t, model):
+        D.broadcast_(m.net.store.params, 0)
+        D.broadcast_(m.net.store.bufs, 0)
+    model_t.net.refresh_derived_in_place(need_dgrad=False)
+    model.net.refresh_derived_in_place(need_dgrad=True)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return route
+
+
+def stop_if_barrier_timeouts(n_local, distributed):
+    """In-kernel barriers of the one-launch BN / GN backward give up after a bounded spin instead of hanging the GPU; a
+    wait that gave up means wrong gradients, so training stops.  The decision is COLLECTIVE (MAX over ranks of the
+    per-device counter): a rank that stopped alone would leave the others waiting in the next gradient all-reduce.
+    Every rank shuts its exchange down and leaves the process group before raising."""
+    n_to = D.max_over_ranks(n_local)
+    if n_to != 0:
+        D.shutdown_exchange()
+        if distributed and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        raise SystemExit("kd6d: %d in-kernel barrier waits timed out (gradients of a step are wrong); "
+                         "re-run with --two_launch_norm_bwd" % n_to)
+    return 0
+

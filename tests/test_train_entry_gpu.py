@@ -197,6 +197,58 @@ def test_train_entry_pipelined_takes_exactly_max_iter_steps(gpu_device, tmp_path
     assert ck["sched"]["last_epoch"] == 7
 
 
+def _train_cmd(root, wd, extra):
+    return [sys.executable, os.path.join(root, "train_kd.py"), "--config_file", "configs/ape.yaml", "--config_file_t",
+            "configs/ape.yaml", "--backbone", "darknet_tiny_h", "--backbone_t", "darknet53", "--kd_weight", "5.",
+            "--working_dir", wd, "--synthetic", "--skip_teacher_eval", "--batch_size", "2", "--image_size", "64"] + extra
+
+
+def test_train_entry_graphs_first_data_parallel_start_one_rank_rehearsal(gpu_device, tmp_path):
+    """train_kd.py's data-parallel start in the grouped launch mode -- graphs recorded BEFORE the communicator, then
+    barrier, kd6d_comm_init, parameter broadcast, in-place refresh of what the recorded kernels read (teacher included),
+    the all-reduce of every step between the two graphs, the collective barrier-timeout check, shutdown -- rehearsed on
+    ONE GPU with --rccl_single_rank (a one-rank process group; bench.py --rccl-single-rank does the same for the bench
+    path).  The run must reach MAX_ITER with the same losses as the run without any process group: at world size 1 the
+    broadcast and the mean all-reduce are identities, and the step is bitwise reproducible."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("dp", ["--rccl_single_rank"]), ("plain", [])):
+        wd = str(tmp_path / tag) + "/"
+        cmd = _train_cmd(root, wd, ["--launch", "pipeline", "--teacher_group", "2", "--max_iters", "50", "--val_freq", "50"] + extra)
+        r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+        assert "Training finished" in r.stdout
+        outs[tag] = r.stdout
+    dp = outs["dp"]
+    i_graphs, i_comm = dp.find("step graphs recorded before the communicator"), dp.find("gradient exchange: ")
+    assert 0 <= i_graphs < i_comm, dp[-2000:]                    # graphs first, communicator second
+    assert re.search(r"gradient exchange: kd6d_comm \(librccl \d+\.\d+\.\d+\)", dp), dp[-2000:]
+    assert "gradient exchange" not in outs["plain"]
+    line = lambda text: [l for l in text.splitlines() if l.startswith("steps: 50/50")]
+    assert line(dp) and line(dp)[0].split("(")[0] == line(outs["plain"])[0].split("(")[0], (line(dp), line(outs["plain"]))
+
+
+def test_train_entry_two_ranks_when_two_gpus_are_visible(gpu_device, tmp_path):
+    """The same start on TWO ranks over RCCL (the first multi-GPU box runs this; it skips itself on a one-GPU box):
+    python -m torch.distributed.run --nproc-per-node 2 train_kd.py --launch pipeline --teacher_group 2.  Both ranks
+    finish and rank 0 reports the kd6d route (global batch sharded, lr = BASE_LR / 2: libs/train_libs.py:117,272)."""
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wd = str(tmp_path) + "/"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577"] + _train_cmd(root, wd, ["--launch", "pipeline", "--teacher_group", "2", "--max_iters",
+                                                             "20", "--val_freq", "20", "--batch_size", "4"])[1:]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1200,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "step graphs recorded before the communicator" in r.stdout and "gradient exchange: kd6d_comm" in r.stdout
+    assert "Training finished" in r.stdout
+
+
 def test_teacher_pnp_gate(gpu_device):
     """postprocess_kd.py:187-202: an image's teacher cells are kept only if RANSAC-PnP recovers a pose from them.
     Image 0's cells vote a consistent pose (0.5 px noise) and stay; image 1's votes are scrambled (60 px) and go."""

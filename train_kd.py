@@ -29,10 +29,10 @@ import torch  # noqa: E402
 from kd6d.arguments.argument_kd import get_args  # noqa: E402
 from kd6d._lib import lib  # noqa: E402
 from kd6d.kd_losses import PackedTargets  # noqa: E402
-from kd6d.libs.distributed import (get_rank, init_exchange, max_over_ranks, shard_batch, shutdown_exchange,  # noqa: E402
-                                   synchronize)
+from kd6d.libs.distributed import get_rank, init_exchange, shard_batch, shutdown_exchange, synchronize  # noqa: E402
 from kd6d.libs.eval_libs import valid  # noqa: E402
-from kd6d.libs.train_libs import build_dataset, build_model, build_model_teacher, dataset_meshes  # noqa: E402
+from kd6d.libs.train_libs import (build_dataset, build_model, build_model_teacher, dataset_meshes,  # noqa: E402
+                                  start_exchange_after_graphs, stop_if_barrier_timeouts)
 from kd6d.models.model_kd import PoseModuleKD as PoseModule  # noqa: E402
 from kd6d.synthetic import make_batch  # noqa: E402
 
@@ -99,16 +99,32 @@ if __name__ == "__main__":
     n_gpu = int(os.environ["WORLD_SIZE"]) if "WORLD_SIZE" in os.environ else 1
     local_rank = int(os.environ.get("LOCAL_RANK", cfg["RUNTIME"]["LOCAL_RANK"]))
     cfg["RUNTIME"]["N_GPU"] = n_gpu
-    cfg["RUNTIME"]["DISTRIBUTED"] = n_gpu > 1
-    cfg_t["RUNTIME"]["DISTRIBUTED"] = n_gpu > 1
+    # --rccl_single_rank: a one-rank process group that still runs the whole data-parallel path (communicator, parameter
+    # broadcast, the all-reduce of every step, the collective stop) -- the rehearsal a one-GPU box allows
+    rehearsal = n_gpu == 1 and cfg["RUNTIME"].get("RCCL_SINGLE_RANK", False)
+    if rehearsal:
+        import socket
+        from kd6d.libs import distributed as _D0
+        _D0.SINGLE_RANK_EXCHANGE = True
+        with socket.socket() as _s:
+            _s.bind(("127.0.0.1", 0))
+            _port = _s.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    cfg["RUNTIME"]["DISTRIBUTED"] = n_gpu > 1 or rehearsal
+    cfg_t["RUNTIME"]["DISTRIBUTED"] = n_gpu > 1 or rehearsal
     device = cfg["RUNTIME"]["RUNNING_DEVICE"]
     if device != "cuda":
         raise SystemExit("the kd6d step runs on MI355X only (--running_device cuda); the CPU restatement "
                          "lives in oracle/ and is test infrastructure")
-    if n_gpu > 1 and hasattr(os, "sched_setaffinity"):
-        # one host thread per rank issues ~1 ms of launches per step: keep it on its own slice of the cores
+    if n_gpu > 1 and hasattr(os, "sched_setaffinity") and int(cfg["RUNTIME"].get("NUM_WORKERS", 0)) == 0:
+        # one host thread per rank issues ~1 ms of launches per step: keep it on its own slice of the cores of this NODE
+        # (LOCAL_WORLD_SIZE ranks share it).  Only without DataLoader workers: they would inherit the narrowed mask.
         cpus = sorted(os.sched_getaffinity(0))
-        per = max(len(cpus) // n_gpu, 1)
+        local_n = int(os.environ.get("LOCAL_WORLD_SIZE", n_gpu))
+        per = max(len(cpus) // max(local_n, 1), 1)
         os.sched_setaffinity(0, cpus[local_rank * per:(local_rank + 1) * per] or cpus)
     torch.cuda.set_device(local_rank)
     if cfg["RUNTIME"].get("TWO_LAUNCH_NORM_BWD"):
@@ -171,6 +187,8 @@ if __name__ == "__main__":
     w_cls, w_reg, w_kd = cfg["SOLVER"]["LOSS_WEIGHT_CLS"], cfg["SOLVER"]["LOSS_WEIGHT_REG"], cfg["KD"]["LOSS_WEIGHT_KD"]
     t0 = time.time()
     launch = cfg["RUNTIME"].get("LAUNCH", "graph")
+    if launch != "pipeline" and int(cfg["RUNTIME"].get("TEACHER_GROUP", 1)) > 1 and get_rank() == 0:
+        print("note: --teacher_group %d is ignored without --launch pipeline" % int(cfg["RUNTIME"]["TEACHER_GROUP"]))
     gstep = None
     if launch != "eager":
         from kd6d.graph import GraphedKDStep, GroupedTeacherKDStep
@@ -190,18 +208,10 @@ if __name__ == "__main__":
         # model builders deferred: rank 0's weights and buffers to every rank, and an eager refresh of what the recorded
         # kernels read of them (bf16 shadow, dgrad packing)
         import itertools
-        from kd6d.libs import distributed as _D
         train_iter = iter(train_loader)
         first = next(train_iter)
-        gstep.prepare(first[0], first[1])
-        synchronize()
-        print("gradient exchange: " + init_exchange())
-        for m in (model_t, model):
-            _D.broadcast_(m.net.store.params, 0)
-            _D.broadcast_(m.net.store.bufs, 0)
-        model.net.invalidate()
-        model.net.prepare_weights(need_dgrad=True)
-        torch.cuda.synchronize()
+        print("step graphs recorded before the communicator (graphs first)")
+        start_exchange_after_graphs(gstep, model_t, model, first)        # kd6d/libs/train_libs.py: the order and why
         train_loader = itertools.chain([first], train_iter)
     MAX_ITER = cfg["SOLVER"]["MAX_ITER"]
     pipelined = gstep is not None and gstep.pipeline
@@ -257,13 +267,7 @@ if __name__ == "__main__":
             # the GPU; a wait that gave up means wrong gradients, so training stops
             # The decision is collective (MAX over ranks of the per-device counter): a rank that stopped alone would
             # leave the others waiting in the next gradient all-reduce.
-            n_to = max_over_ranks(lib.kd6d_barrier_timeouts())
-            if n_to != 0:
-                shutdown_exchange()
-                if cfg["RUNTIME"]["DISTRIBUTED"]:
-                    torch.distributed.destroy_process_group()
-                raise SystemExit("kd6d: %d in-kernel barrier waits timed out (gradients of a step are wrong); "
-                                 "re-run with --two_launch_norm_bwd" % n_to)
+            stop_if_barrier_timeouts(lib.kd6d_barrier_timeouts(), cfg["RUNTIME"]["DISTRIBUTED"])
         if get_rank() == 0 and total_steps % VAL_FREQ == 0:
             acc = valid(cfg, total_steps, valid_loader, model, device, valid_meshes, logger=logger)     # train_kd.py:148-150
             model.train()
