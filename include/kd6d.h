@@ -77,16 +77,19 @@ int kd6d_abi_version(void);
  *   activations and loss values, KD6D_ACC_GRAD for everything summed in the reverse sweep.  Zero-initialised by the
  *   caller (the engine zeroes its whole statistics arena once per step), only ever added to; a non-finite addend
  *   poisons it (the value reads as NaN).  Arrays of kd6d_acc are INTERLEAVED {lo, hi} per element.
- *   Gradient outputs (dw / dbias of kd6d_conv2d_wgrad, dgamma / dbeta of kd6d_gn_relu_bwd, dseg_scale of
+ *   Small gradient outputs (dbias of kd6d_conv2d_wgrad, dgamma / dbeta of kd6d_gn_relu_bwd, dseg_scale of
  *   kd6d_loss_backward) use the PLANAR layout instead: `int64_t* acc` + `acc_hi_stride`, word lo of element i at
- *   acc[i], word hi at acc[i + acc_hi_stride] (a wave's 64 lo words are then contiguous: tile flushes are 2-4x
- *   faster than interleaved).  The engine keeps ONE such accumulator image of its flat gradient bucket (lo plane then
- *   hi plane) and turns it into fp32 gradients once per step with kd6d_grad_acc_resolve.
+ *   acc[i], word hi at acc[i + acc_hi_stride].  The engine keeps ONE such accumulator image of its flat gradient bucket
+ *   (lo plane then hi plane).  Per-layer WEIGHT gradients use no atomics at all: every pixel split of the launch
+ *   stores its partial dW image into a caller-owned slab (plain stores, 4-5x the byte rate of atomic adds) and the
+ *   splits are added in a fixed order.  kd6d_grad_acc_resolve turns both kinds into fp32 gradients, one launch at the
+ *   end of the reverse sweep.
  * kd6d_acc_read: out[i] (=, or += when accumulate != 0) value(acc[i]) for n interleaved accumulators of class
- * `kind`; clear != 0 zeroes them afterwards.  kd6d_grad_acc_resolve: for every region r of desc_dev (int64 triples
- * {first element, element count, first workgroup}; total_blocks workgroups of 1024 elements each, regions in ascending
- * block order) grads[e] += value(acc planar element e, class KD6D_ACC_GRAD) and the accumulator is cleared -- one
- * launch at the end of the reverse sweep. */
+ * `kind`; clear != 0 zeroes them afterwards.  kd6d_grad_acc_resolve: desc_dev holds n_regions int64 quintuples
+ * {first element, element count, first workgroup, parts, slab address}, regions in ascending workgroup order,
+ * total_blocks workgroups of 1024 elements each.  parts == 0: grads[e] += value(planar accumulator of element e, class
+ * KD6D_ACC_GRAD), accumulator cleared.  parts >= 1: grads[first + i] += slab[0][i] + slab[1][i] + ... (that order),
+ * slab = `parts` partial images of `count` floats each (what kd6d_conv2d_wgrad wrote). */
 typedef struct kd6d_acc { int64_t lo, hi; } kd6d_acc;
 /* Workspace of a launch that reduces to ONE fp32 scalar (kd6d_focal_fwd, kd6d_student_points' loss_reg, kd6d_sumsq):
  * 32 bytes, pre-zeroed; the launch's LAST workgroup converts the fixed-point total and WRITES the scalar (the running
@@ -199,15 +202,18 @@ int kd6d_conv2d_fwd_block(const kd6d_conv_geom* g, int dtype, const void* x, con
 int kd6d_conv2d_dgrad(const kd6d_conv_geom* g, int dtype, const void* dy,
                       const void* wt, void* dx, int accumulate, void* stream);
 
-/* dw[cout][ky][kx][cin] += sum_pixels dy (x) x, into PLANAR gradient accumulators (class KD6D_ACC_GRAD, see
- * "reproducible reductions": dw_acc[i] / dw_acc[i + acc_hi_stride]; pre-zeroed or holding a running sum).
- * dbias_acc (optional): += sum_pixels dy, the bias gradient of the same layer, taken from the dY tiles the kernel
- * stages anyway (same layout and stride).
- * cu_budget: how many compute units this launch should aim to fill (0 = the whole device).  The pixel
- * axis is split over workgroups and every split ends in an atomic flush of its dW tile, so a caller that
- * keeps k weight gradients in flight on k streams passes CUs/k: same k-loop work, 1/k of the flushes. */
-int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy, int64_t* dw_acc,
-                      int64_t* dbias_acc, int64_t acc_hi_stride, int cu_budget, void* stream);
+/* Weight gradient dw[cout][ky][kx][cin] = sum_pixels dy (x) x as PARTIAL IMAGES: the pixel axis is split over
+ * workgroups and split s stores its partial dW, all cout*k*k*cin floats, at dw_slab + s * cout*k*k*cin (plain stores;
+ * every element of every part is written).  kd6d_conv2d_wgrad_parts() tells how many parts the launch writes for a
+ * geometry, dtype, bias flag and cu_budget (>= 1; a deterministic function of its arguments and the device);
+ * slab_floats is checked against it.  The caller adds the parts in order (kd6d_grad_acc_resolve; "reproducible
+ * reductions").  dbias_acc (optional): += sum_pixels dy, the bias gradient of the same layer, taken from the dY tiles the
+ * kernel stages anyway, into PLANAR accumulators (class KD6D_ACC_GRAD, stride acc_hi_stride).
+ * cu_budget: how many compute units this launch should aim to fill (0 = the whole device): a caller that keeps k
+ * weight gradients in flight on k streams passes CUs/k -- same k-loop work, 1/k of the partial images. */
+int kd6d_conv2d_wgrad_parts(const kd6d_conv_geom* g, int dtype, int with_bias, int cu_budget);
+int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy, float* dw_slab,
+                      int64_t slab_floats, int64_t* dbias_acc, int64_t acc_hi_stride, int cu_budget, void* stream);
 
 /* wt[cin][ky][kx][cout] <- w[cout][ky][kx][cin] for n_layers layers in one
  * launch.  desc_dev: int32[n_layers*6] = {w_off, wt_off, cout, cin, ksize,

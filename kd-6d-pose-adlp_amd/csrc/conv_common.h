@@ -59,6 +59,9 @@ struct ConvParams {
   float* slab;         // split-K: fp32 partial tiles, slab[split][M][N] (kd6d_conv2d_fwd workspace)
   int nk_split;        // k-steps per split
   int stats_cpg_shift; // log2(channels per group): 2 or 3
+  int stats_skip;      // group statistics: bit s set = level s is NOT summed by the epilogue (its rows do not fall into whole
+                       // 16-row fragments of one image: H*W or its first row not a multiple of 16); the host sums those levels
+                       // with a separate gn_stats launch behind the convolution (set_stats / stats_followup)
   // ---- normalisation + activation fused behind the convolution (conv_epilogue_norm; kd6d_conv2d_fwd_norm) ----
   void* norm_dst;              // non-null: once the statistics are complete across workgroups, act(norm(v)) goes here (T)
   const float* norm_gamma;
@@ -147,7 +150,7 @@ __device__ __forceinline__ int tile_of_workgroup(const ConvParams& p, int bid, i
 }
 
 // (level, image) key of GEMM row m: level * batch + image.  Monotone in m (levels are packed level-major, image-major).
-__device__ __forceinline__ int stats_key(const ConvParams& p, int m) {
+__device__ __forceinline__ int stats_key(const ConvParams& p, int m, int* level = nullptr) {
   int mb = 0, hw = 1, sg = 0;
   float inv = 1.f;
 #pragma unroll
@@ -155,6 +158,7 @@ __device__ __forceinline__ int stats_key(const ConvParams& p, int m) {
     if (s < p.nseg && m >= p.seg[s].m_begin) {
       mb = p.seg[s].m_begin; hw = p.seg[s].dst_hw; sg = s; inv = p.seg[s].inv_hw;
     }
+  if (level) *level = sg;
   return sg * p.batch + fast_div(m - mb, hw, inv);
 }
 
@@ -210,8 +214,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 //   plain stores -> a thread per channel adds the WP slots in order -> one global integer atomic per channel and workgroup.
 //   Group mode (GroupNorm): a 16-pixel fragment normally lies inside one (level, image): its 4-channel lane sums are
 //   DPP-summed over the fragment's rows and staged (one entry per writer lane), a rolled loop adds the entries to the LDS
-//   accumulator table [image of the tile][group of the tile]; fragments that straddle images (levels whose H*W is not a
-//   multiple of 16) are staged row by row in 16 more passes.  One flush of the table per workgroup.
+//   accumulator table [image of the tile][group of the tile]; one flush of the table per workgroup.  Levels whose rows do
+//   not fall into whole fragments of one image (H*W not a multiple of 16: the 2 x 2 level of 256^2 crops, 15 x 20 and
+//   4 x 5 of full frames) are skipped here (ConvParams::stats_skip) and summed by a small gn_stats launch the host
+//   issues behind the convolution -- handling them in this epilogue cost the halo tiles 10-30 registers.
 // `red_f32`: the dead staging buffers.
 template <int BP, int BC, int WP, int WC, bool NORM = false>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t (&acc)[BC / WC / 16][BP / WP / 16],
@@ -269,87 +275,60 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvParams& p, f32x4_t
   }
   // ---- group mode ----
   constexpr int NW = WP * WC;
-  constexpr int NENT = NW * PI * CI * 4;   // staged entries of one pass: (wave, fragment q, channel tile c, lane quarter fq)
+  constexpr int NENT = NW * PI * CI * 4;   // staged entries: (wave, fragment q, channel tile c, lane quarter fq)
   const int G = p.stats_groups;
   const int cs = p.stats_cpg_shift;        // 4 or 8 channels per group: a lane's 4 aligned channels share one
   const int GT = BC >> cs;                 // groups touched by this channel tile
-  auto key_of = [&](int m) { return stats_key(p, m); };
   const int m_last = (m0 + BP < p.M ? m0 + BP : p.M) - 1;
-  const int key_lo = key_of(m0);
-  const int nkeys = key_of(m_last) - key_lo + 1;
+  const int key_lo = stats_key(p, m0);
+  const int nkeys = stats_key(p, m_last) - key_lo + 1;
   const int tab = nkeys * GT * 2;          // accumulators {sum, sumsq} per (key, group): 16 bytes each
-  // LDS image: table | staged entries (float2) | fragment keys | row keys | flag
+  // LDS image: accumulator table | staged entries | fragment keys
   long long* table = reinterpret_cast<long long*>(red_f32);
   f32x2_t* ent = reinterpret_cast<f32x2_t*>(table + 2 * tab);
-  int* fragkey = reinterpret_cast<int*>(ent + NENT);       // key of a uniform fragment, -1: rows of several images
-  int* rowkey = fragkey + NW * PI;                         // pass j >= 0: key of row j of a non-uniform fragment
-  int* nonuni = rowkey + NW * PI;
+  int* fragkey = reinterpret_cast<int*>(ent + NENT);
   const int wave = wp * WC + wc;
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * tab; i += blockDim.x) table[i] = 0;
-  if (threadIdx.x == 0) *nonuni = 0;
-  // this lane's fragments: row key, uniformity (bit q of umask)
-  int keyq[PI];
-  unsigned umask = 0;
+  // phase A (accumulators live): a fragment of 16 rows lies inside ONE image of a level the epilogue sums (the host
+  // leaves the levels where that does not hold to a separate launch: ConvParams::stats_skip) or contributes nothing: its
+  // 4-channel lane sums are DPP-summed over the rows and staged, one entry per 4-channel slice, plain stores
 #pragma unroll
   for (int q = 0; q < PI; ++q) {
-    const int m = m0 + wp * (BP / WP) + q * 16 + fr;
-    const bool mok = m < p.M;
-    keyq[q] = mok ? key_of(m) - key_lo : -1;
-    const int key0 = __shfl(keyq[q], lane & 48, 64);
-    if (__all(!mok || keyq[q] == key0)) umask |= 1u << q;       // rows past M sit at the tail of the last fragment
+    const int mf = m0 + wp * (BP / WP) + q * 16;         // first row of the fragment (a multiple of 16)
+    int level = 0;
+    const int key0 = stats_key(p, mf < p.M ? mf : p.M - 1, &level) - key_lo;
+    const bool live = mf < p.M && !((p.stats_skip >> level) & 1);
+    if (lane == 0 && wc == 0) fragkey[wp * PI + q] = live ? key0 : -1;
+    const bool mok = live && mf + fr < p.M;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int nl = wc * (BC / WC) + c * 16 + fq * 4;
+      const bool ok = mok && n0 + nl < p.N;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ok ? acc[c][q][r] : 0.f;
+        s1 += v;
+        s2 += v * v;
+      }
+      s1 = row16_sum(s1);
+      s2 = row16_sum(s2);
+      if (fr == 0) ent[((wave * PI + q) * CI + c) * 4 + fq] = f32x2_t{s1, s2};
+    }
   }
   __syncthreads();
-  // pass -1: the uniform fragments, one entry per 4-channel slice (DPP row sum); passes 0..15 (only when the tile holds
-  // a non-uniform fragment): row j of every non-uniform fragment, one entry per lane of that row
-  for (int j = -1; j < 16; ++j) {
-    if (j >= 0) {
-      if (*nonuni == 0) break;             // block-uniform: written before the barrier that ended pass -1
-      __syncthreads();                     // the previous pass has consumed the entries
-    }
-#pragma unroll
-    for (int q = 0; q < PI; ++q) {
-      const bool uni = (umask >> q) & 1u;
-      const bool mine = j < 0 ? (uni && fr == 0) : (!uni && fr == j);
-      if (fq == 0 && wc == 0 && (j < 0 ? fr == 0 : mine)) {
-        if (j < 0) {
-          fragkey[wp * PI + q] = uni ? (keyq[q] < 0 ? 0 : keyq[q]) : -1;
-          if (!uni) *nonuni = 1;
-        } else {
-          rowkey[wp * PI + q] = keyq[q];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CI; ++c) {
-        const int nl = wc * (BC / WC) + c * 16 + fq * 4;
-        const bool ok = keyq[q] >= 0 && n0 + nl < p.N;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = ok ? acc[c][q][r] : 0.f;
-          s1 += v;
-          s2 += v * v;
-        }
-        if (j < 0 && uni) {                // wave-uniform condition: the DPP sum runs with every lane enabled
-          s1 = row16_sum(s1);
-          s2 = row16_sum(s2);
-        }
-        if (mine) ent[((wave * PI + q) * CI + c) * 4 + fq] = f32x2_t{s1, s2};
-      }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < NENT; e += blockDim.x) {
-      const int efq = e & 3, ec = (e >> 2) % CI, eq = ((e >> 2) / CI) % PI, ew = (e >> 2) / (CI * PI);
-      const int ewp = ew / WC, ewc = ew - ewp * WC;
-      const int fk = fragkey[ewp * PI + eq];
-      const int key = j < 0 ? fk : (fk < 0 ? rowkey[ewp * PI + eq] : -1);
-      if (key < 0) continue;               // not this pass's kind of fragment, or a row past M
-      const int nl = ewc * (BC / WC) + ec * 16 + efq * 4;
-      const f32x2_t v = ent[e];
-      long long* o2 = table + ((key * GT + (nl >> cs)) << 2);
-      det_add_lds<KD6D_DET_ACT>(o2, v[0]);
-      det_add_lds<KD6D_DET_ACT>(o2 + 2, v[1]);
-    }
+  // phase B (accumulators dead): the staged entries -> the accumulator table, integer LDS atomics (order-free)
+  for (int e = threadIdx.x; e < NENT; e += blockDim.x) {
+    const int efq = e & 3, ec = (e >> 2) % CI, eq = ((e >> 2) / CI) % PI, ew = (e >> 2) / (CI * PI);
+    const int ewp = ew / WC, ewc = ew - ewp * WC;
+    const int key = fragkey[ewp * PI + eq];
+    if (key < 0) continue;
+    const int nl = ewc * (BC / WC) + ec * 16 + efq * 4;
+    const f32x2_t v = ent[e];
+    long long* o2 = table + ((key * GT + (nl >> cs)) << 2);
+    det_add_lds<KD6D_DET_ACT>(o2, v[0]);
+    det_add_lds<KD6D_DET_ACT>(o2 + 2, v[1]);
   }
   __syncthreads();
   const int g_first = n0 >> cs;
@@ -860,6 +839,11 @@ static inline bool plan_only(int grid, int threads, size_t lds, bool fused_epilo
   return true;
 }
 
+// conv_igemm.hip: group statistics of the levels the epilogue skips (ConvParams::stats_skip), from the stored tensor
+int stats_followup(const ConvParams& p, bool dst_f32, hipStream_t st);
+// norm_ops.hip: {sum, sum of squares} per (level, image, group) of the levels in `mask` of a packed NHWC tensor
+int gn_stats_levels(int src_f32, const void* y, const int* row0, const int* hw, int nseg, int batch, int C, int G,
+                    unsigned mask, long long* stats, hipStream_t st);
 // conv_halo.hip: the 3x3 / stride 1 halo-patch kernel takes the layer (returns false: not its shape / too few tiles)
 bool dispatch_halo_fwd(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st);
 bool dispatch_halo_dgrad(const ConvParams& p, const kd6d_conv_geom* g, hipStream_t st);

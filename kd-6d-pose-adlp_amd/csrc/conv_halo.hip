@@ -466,5 +466,9 @@ extern "C" int kd6d_conv2d_pair_end(void) {
     for (int i = 0; i < n; ++i) g_pair.rec[i].single(g_pair.rec[i]);
   }
   KD6D_CHECK_LAUNCH("kd6d_conv2d_pair_end");
+  for (int i = 0; i < n; ++i) {      // group statistics of the levels the epilogue leaves to a separate pass (bf16 kernel)
+    const int rc = kd6d_detail::stats_followup(g_pair.rec[i].q, g_pair.rec[i].q.out_f32 != 0, g_pair.rec[i].st);
+    if (rc) return rc;
+  }
   return KD6D_OK;
 }

@@ -30,8 +30,20 @@ namespace {
 // T -- so the separate normalise launch and its (rows, C) round trip go without any wait inside a kernel.  The
 // activation tensor the weight gradient needs is written on the way (centre tap, channel tile 0: every input pixel
 // exactly once); workgroup 0 publishes save_mean / save_invstd and updates the running statistics.
+// Waves per SIMD the register allocation must leave room for (second __launch_bounds__ argument on AMD): the tiles whose
+// LDS lets 2 / 5 workgroups share a CU sit a few registers under that occupancy step, and without the hint the compiler
+// spreads into AGPRs past it (round 4: the statistics epilogue grew by 8 VGPRs and 128 x 128 fell from 2 workgroups per CU
+// to 1: 33 -> 52 us per launch).  0 = no constraint.
+template <typename T, int BP, int BC, bool XF, bool NORM>
+constexpr int igemm_min_waves() {
+  if (XF || NORM) return 1;
+  if (BP == 128 && BC == 128) return 2;
+  if (BP == 64 && BC == 64 && sizeof(T) == 2) return 5;
+  return 1;
+}
+
 template <typename T, int BP, int BC, int WP, int WC, int MODE, bool XF = false, bool NORM = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (igemm_min_waves<T, BP, BC, XF, NORM>())) void conv_igemm_kernel(const ConvParams p) {
   constexpr int EG = Granule<T>::N;
   constexpr int BK = 8 * EG;
   constexpr int PI = BP / WP / 16;
@@ -255,7 +267,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // ---------------------------------------------------------------------------
 
 template <int BP, int BC, int WP, int WC, int MODE, int NSTAGE, bool SPLIT = false>
-__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (SPLIT ? 1 : (BP == 128 && BC == 128) ? 2 : (BP == 64 && BC == 64) ? 5 : 1))
+void conv_igemm_glds_kernel(const ConvParams p) {
   using T = bf16_t;
   constexpr int BK = 64;
   constexpr int PI = BP / WP / 16;
@@ -513,7 +526,7 @@ __device__ __forceinline__ int smallc_swz(int row) {
 }
 
 template <int CG, int NB, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_smallc_kernel(const ConvParams p, int halo, int total_rows,
+__global__ __launch_bounds__(256, (NB == 1 ? 7 : 1)) void conv3x3_smallc_kernel(const ConvParams p, int halo, int total_rows,
                                                              int patch_bytes, int wbytes) {
   using T = bf16_t;
   constexpr int BP = 256;
@@ -634,8 +647,10 @@ __global__ __launch_bounds__(256) void conv3x3_smallc_kernel(const ConvParams p,
 // Weight gradient:  dW[n][j] += sum_m dY[m][n] * im2col(X)[m][j],  j = (tap, ci).
 // Both operands are reduced along the pixel axis, which is the slow axis of NHWC,
 // so tiles are staged TRANSPOSED into the same 128-B-row LDS image (row = channel,
-// k = pixel) and consumed by the identical fragment reads.  The partial tiles of the pixel splits meet in the
-// gradient bucket's PLANAR fixed-point accumulators (kd6d_det.h: integer atomics, bitwise reproducible).
+// k = pixel) and consumed by the identical fragment reads.  The pixel axis is split over workgroups; every split leaves
+// its partial dW image [cout][j] in the caller's SLAB with plain stores (slab[split][cout][j]) and the caller adds the
+// splits in a fixed order (kd6d_grad_acc_resolve at the end of the reverse sweep): bitwise reproducible, and a plain
+// store moves 4-5x the bytes per second of an atomic add.
 // ---------------------------------------------------------------------------
 struct WgradParams {
   int nseg, batch;
@@ -648,9 +663,11 @@ struct WgradParams {
   SegDev seg[kMaxSeg];
   const void* x;
   const void* dy;
-  long long* dw;      // planar accumulators: word lo of element i at dw[i], word hi at dw[i + acc_hi]
-  long long* dbias;   // optional: += column sums of dY (bias gradient), accumulated by the j-tile-0 workgroups
-  long long acc_hi;
+  float* dw;          // slab: partial image of split s at dw + s * Cout * J (plain stores)
+  long long slab_floats;
+  int* plan_splits;   // host: non-null = dry run, the launch function reports its number of partial images here
+  long long* dbias;   // optional: += column sums of dY (bias gradient), planar accumulators (hi word at + acc_hi),
+  long long acc_hi;   //           added by the j-tile-0 workgroups
   int cu_budget;  // CUs this launch should aim to fill (callers that run several weight gradients side by side)
 };
 
@@ -849,11 +866,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
   }
   __syncthreads();
+  float* part = p.dw + (size_t)blockIdx.y * (size_t)p.Cout * (size_t)p.J;
   for (int i = tid; i < BN * BJ; i += 256) {
     const int nl = i / BJ, jl = i - nl * BJ;
     const int n = n0 + nl, j = j0 + jl;
-    if (n < p.Cout && j < p.J)
-      det_add_planar<KD6D_DET_GRAD>(p.dw + (size_t)n * (size_t)p.J + (size_t)j, p.acc_hi, et[i]);
+    if (n < p.Cout && j < p.J) part[(size_t)n * (size_t)p.J + (size_t)j] = et[i];
   }
 }
 
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
       if (n0 + i < p.Cout) det_add_words_planar(p.dbias + n0 + i, p.acc_hi, bred[2 * i], bred[2 * i + 1]);
     __syncthreads();
   }
-  // ---- epilogue: [n][j] fp32 image in LDS, then rows of 64 consecutive accumulators per wave instruction ----
+  // ---- epilogue: [n][j] fp32 image in LDS, then rows of 256 contiguous bytes per wave store ----
   float* et = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int a = 0; a < NI; ++a)
@@ -1068,6 +1085,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
       for (int r = 0; r < 4; ++r) et[(nl + r) * EP + jl] = acc[a][b][r];
     }
   __syncthreads();
+  float* part = p.dw + (size_t)blockIdx.y * (size_t)p.Cout * (size_t)p.J;      // this split's partial image
   for (int nl = wave; nl < BN; nl += 4) {
     const int n = n0 + nl;
     if (n >= p.Cout) break;
@@ -1075,7 +1093,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
     for (int h = 0; h < BJ / 64; ++h) {
       const int jl = h * 64 + lane;
       const int j = j0 + jl;
-      if (j < p.J) det_add_planar<KD6D_DET_GRAD>(p.dw + (size_t)n * (size_t)p.J + (size_t)j, p.acc_hi, et[nl * EP + jl]);
+      if (j < p.J) part[(size_t)n * (size_t)p.J + (size_t)j] = et[nl * EP + jl];
     }
   }
 }
@@ -1205,9 +1223,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradParams
     for (int r = 0; r < 4; ++r) et[(nb * 16 + fq * 4 + r) * JP + jb * 16 + fr] = acc[i][r];
   }
   __syncthreads();
+  float* part = p.dw + (size_t)blockIdx.x * (size_t)p.Cout * J;      // one partial image per (persistent) workgroup
   for (int i = tid; i < NB * 16 * JP; i += 256) {
     const int n = i / JP, j = i - n * JP;
-    if (n < p.Cout && j < J) det_add_planar<KD6D_DET_GRAD>(p.dw + (size_t)n * J + j, p.acc_hi, et[i]);
+    if (n < p.Cout && j < J) part[(size_t)n * J + j] = et[i];
   }
 }
 
@@ -1466,6 +1485,14 @@ void dispatch_igemm(const ConvParams& p, hipStream_t st) {
   }
 }
 
+// dry run (p.plan_splits): report the number of partial images; else check the slab holds them (error flag otherwise)
+thread_local bool g_wgrad_slab_short = false;
+bool wgrad_slab_ok(const WgradParams& p, int parts) {
+  if (p.plan_splits) { *p.plan_splits = parts; return false; }
+  if ((long long)parts * p.Cout * p.J > p.slab_floats) { g_wgrad_slab_short = true; return false; }
+  return true;
+}
+
 template <typename T, int BN, int BJ, int WN, int WJ>
 void launch_wgrad(const WgradParams& p, hipStream_t st) {
   constexpr int BKM = 8 * Granule<T>::N;
@@ -1482,6 +1509,7 @@ void launch_wgrad(const WgradParams& p, hipStream_t st) {
   int steps_per = (steps_total + splits - 1) / splits;
   q.m_chunk = steps_per * BKM;
   splits = (p.M + q.m_chunk - 1) / q.m_chunk;
+  if (!wgrad_slab_ok(p, splits)) return;
   const size_t lds = (size_t)(BN + BJ) * 128 * 2;
   auto kern = conv_wgrad_kernel<T, BN, BJ, WN, WJ>;
   static bool attr_set = false;
@@ -1501,22 +1529,23 @@ void launch_wgrad_tr(const WgradParams& p, hipStream_t st) {
   const int ntiles = (p.Cout + BN - 1) / BN;
   const int tiles = q.n_jtiles * ntiles;
   const int steps_total = (p.M + BKM - 1) / BKM;
-  // time ~ (steps/S) * t_step + S * |dW| / (atomic rate: 1.3 TB/s measured for fp32 adds in rounds 1-3; the 64-bit
-  // integer adds of the reproducible accumulators move twice the bytes per element at 0.6-0.75x the element rate,
-  // tools/microbench/atomic_rate.hip), t_step ~ 1.6 us measured
+  // time ~ (steps/S) * t_step + S * |dW| / (flush rate), t_step ~ 1.6 us measured.  A split's partial image costs a plain
+  // store here (~6 TB/s) and a read by kd6d_grad_acc_resolve at the end of the sweep (~4 TB/s): 2.4 TB/s together (the fp32
+  // atomic flush of rounds 1-3: 1.3 TB/s)
   //   => S* = sqrt(steps * t_step * rate / |dW|); at most 2 workgroups per CU, because many
   //   workgroups adding into one small dW are contention-bound (measured: 2048 -> 512 = -25 %)
   // a caller that keeps several weight gradients in flight asks each for a fraction of the device: fewer,
   // longer splits -> proportionally fewer atomic tile flushes for the same k-loop work
   const double frac = (double)p.cu_budget / (double)cached_cu_count();
   const double dw_bytes = (double)p.Cout * (double)p.J * 4.0;
-  int splits = (int)(frac * sqrt((double)steps_total * 2.08e6 / dw_bytes) + 0.5);
+  int splits = (int)(frac * sqrt((double)steps_total * 3.8e6 / dw_bytes) + 0.5);
   if (splits > 512 / tiles) splits = 512 / tiles;
   if (splits > steps_total / 2) splits = steps_total / 2;
   if (splits < 1) splits = 1;
   const int steps_per = (steps_total + splits - 1) / splits;
   q.m_chunk = steps_per * BKM;
   splits = (p.M + q.m_chunk - 1) / q.m_chunk;
+  if (!wgrad_slab_ok(p, splits)) return;
   const size_t stage = (size_t)2 * 2 * BKM * 256;
   const size_t epi = (size_t)BN * (BJ + 4) * 4;
   const size_t lds = stage > epi ? stage : epi;
@@ -1543,6 +1572,7 @@ void launch_wgrad_small(const WgradParams& p, int R, hipStream_t st) {
   const int ntiles = p.batch * tiles_per_img;
   int grid = 2 * p.cu_budget;                                  // persistent: one flush per workgroup
   if (grid > ntiles) grid = ntiles;
+  if (!wgrad_slab_ok(p, grid)) return;
   constexpr int JB_ = (KS * KS * 8 * CG + 15) / 16;
   const size_t image = (size_t)NB * 16 * JB_ * 16 * sizeof(float);      // the flush's [n][j] image
   const size_t lds = (size_t)2 * buf_bytes > image ? (size_t)2 * buf_bytes : image;
@@ -1649,12 +1679,33 @@ int set_stats(const kd6d_conv_geom* g, ConvParams& p, kd6d_acc* stats, int stats
                  "%s: fused group statistics need 4 or 8 channels per group (cout=%d, groups=%d)", who, g->cout,
                  stats_groups);
   p.stats = reinterpret_cast<long long*>(stats); p.stats_groups = stats_groups;
-  if (stats_groups > 0) p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
+  p.stats_skip = 0;
+  if (stats_groups > 0) {
+    p.stats_cpg_shift = (g->cout / stats_groups) == 8 ? 3 : 2;
+    // the epilogue sums whole 16-row fragments that lie inside one image; a level where that does not hold is left to
+    // stats_followup()
+    for (int s2 = 0; s2 < p.nseg; ++s2)
+      if ((p.seg[s2].dst_hw % 16) != 0 || (p.seg[s2].m_begin % 16) != 0) p.stats_skip |= 1 << s2;
+  }
   return KD6D_OK;
 }
 
 // Would kd6d_conv2d_fwd_norm take the fused path?  Dry run of the dispatch with the fields that steer it set the way
 // the real call sets them, then the residency rule of kd6d_barrier.h.
+}  // namespace
+
+// The levels the epilogue's group statistics skip (ConvParams::stats_skip): summed from the stored tensor by a small
+// gn_stats launch behind the convolution (norm_ops.hip).  Also called by the pair bracket (conv_halo.hip) for the
+// launches it deferred.
+int kd6d_detail::stats_followup(const ConvParams& p, bool dst_f32, hipStream_t st) {
+  if (!p.stats || p.stats_groups <= 0 || p.stats_skip == 0) return KD6D_OK;
+  int row0[kMaxSeg] = {0}, hw[kMaxSeg] = {0};
+  for (int s2 = 0; s2 < p.nseg; ++s2) { row0[s2] = p.seg[s2].dst_row0; hw[s2] = p.seg[s2].dst_hw; }
+  return gn_stats_levels(dst_f32 ? 1 : 0, p.dst, row0, hw, p.nseg, p.batch, p.N, p.stats_groups, (unsigned)p.stats_skip,
+                         p.stats, st);
+}
+
+namespace {
 bool norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups, ConvParams& p, LaunchPlan& plan) {
   // option conv.fuse_norm: bit 0 = GroupNorm launches, bit 1 = BatchNorm launches
   if (((int)kd6d_opt(KD6D_OPT_CONV_FUSE_NORM) & (kind == KD6D_NORM_GROUP ? 1 : 2)) == 0) return false;
@@ -1663,6 +1714,7 @@ bool norm_fusable(const kd6d_conv_geom* g, int dtype, int kind, int groups, Conv
   static kd6d_acc dummy_acc;
   if (set_stats(g, p, &dummy_acc, kind == KD6D_NORM_GROUP ? groups : 0, "kd6d_conv2d_fwd_norm") != KD6D_OK) return false;
   if (kind == KD6D_NORM_GROUP && groups <= 0) return false;
+  if (p.stats_skip) return false;       // a level whose statistics need the separate pass: nothing to wait for in-kernel
   p.norm_dst = &dummy;
   p.out_f32 = 1;
   g_launch_plan = &plan;
@@ -1709,8 +1761,13 @@ extern "C" int kd6d_conv2d_fwd(const kd6d_conv_geom* g, int dtype, const void* x
     rc = set_stats(g, p, stats, stats_groups, "kd6d_conv2d_fwd");
     if (rc) return rc;
   }
+  const int pending = kd6d_conv2d_pair_pending();
   dispatch_fwd(p, g, dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   KD6D_CHECK_LAUNCH("kd6d_conv2d_fwd");
+  if (p.stats_skip && kd6d_conv2d_pair_pending() == pending) {       // launched (not recorded by a pair bracket)
+    rc = stats_followup(p, p.out_f32 || dtype == KD6D_F32, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+  }
   return KD6D_OK;
 }
 
@@ -1829,37 +1886,66 @@ namespace kd6d_detail {
 int colsum_grad_planar(int dtype, const void* x, int64_t rows, int C, long long* acc, long long acc_hi, void* stream);
 }
 
-extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy,
-                                 int64_t* dw, int64_t* dbias, int64_t acc_hi_stride, int cu_budget, void* stream) {
-  int rc = check_geom(g, dtype, "kd6d_conv2d_wgrad");
+namespace {
+int wgrad_params(const kd6d_conv_geom* g, int dtype, int cu_budget, const char* who, WgradParams& p) {
+  int rc = check_geom(g, dtype, who);
   if (rc) return rc;
-  KD6D_CHECK_ARG(x && dy && dw, "kd6d_conv2d_wgrad: null tensor pointer");
-  KD6D_CHECK_ARG(acc_hi_stride != 0, "kd6d_conv2d_wgrad: acc_hi_stride = 0 (planar accumulators: lo plane, hi plane)");
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
-  KD6D_CHECK_ARG(g->cout % eg == 0, "kd6d_conv2d_wgrad: cout=%d must be a multiple of %d", g->cout, eg);
-  WgradParams p;
+  KD6D_CHECK_ARG(g->cout % eg == 0, "%s: cout=%d must be a multiple of %d", who, g->cout, eg);
   memset(&p, 0, sizeof(p));
   p.nseg = g->nseg; p.batch = g->batch; p.Cin = g->cin; p.Cout = g->cout;
   p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad;
   p.J = g->ksize * g->ksize * g->cin;
-  KD6D_CHECK_ARG(fill_segs(g, false, p.seg, &p.M), "kd6d_conv2d_wgrad: grid too large");
+  KD6D_CHECK_ARG(fill_segs(g, false, p.seg, &p.M), "%s: grid too large", who);
   for (int s = 0; s < g->nseg; ++s)
-    KD6D_CHECK_ARG(p.seg[s].dst_row0 == p.seg[s].m_begin,
-                   "kd6d_conv2d_wgrad: output levels must be packed back to back");
-  p.x = x; p.dy = dy;
-  p.dw = reinterpret_cast<long long*>(dw); p.dbias = reinterpret_cast<long long*>(dbias); p.acc_hi = (long long)acc_hi_stride;
+    KD6D_CHECK_ARG(p.seg[s].dst_row0 == p.seg[s].m_begin, "%s: output levels must be packed back to back", who);
   const int ncu = cached_cu_count();
-  KD6D_CHECK_ARG(cu_budget >= 0, "kd6d_conv2d_wgrad: cu_budget=%d", cu_budget);
+  KD6D_CHECK_ARG(cu_budget >= 0, "%s: cu_budget=%d", who, cu_budget);
   p.cu_budget = (cu_budget == 0 || cu_budget > ncu) ? ncu : cu_budget;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return KD6D_OK;
+}
+void wgrad_dispatch(const WgradParams& p, const kd6d_conv_geom* g, int dtype, hipStream_t st) {
   if (dtype == KD6D_BF16) {
     if (!dispatch_wgrad_small(p, g, st)) dispatch_wgrad_tr(p, st);
   } else {
     dispatch_wgrad<float>(p, st);
-    if (dbias) {           // exact-fp32 parity path: separate column-sum pass
-      rc = kd6d_detail::colsum_grad_planar(dtype, dy, p.M, g->cout, p.dbias, p.acc_hi, stream);
-      if (rc) return rc;
-    }
+  }
+}
+}  // namespace
+
+extern "C" int kd6d_conv2d_wgrad_parts(const kd6d_conv_geom* g, int dtype, int with_bias, int cu_budget) {
+  WgradParams p;
+  int rc = wgrad_params(g, dtype, cu_budget, "kd6d_conv2d_wgrad_parts", p);
+  if (rc) return rc;
+  int parts = 0;
+  p.plan_splits = &parts;
+  // (the narrow-layer kernel takes no bias gradient: the same dispatch decision as the real call)
+  static long long dummy_bias;
+  p.dbias = with_bias ? &dummy_bias : nullptr;
+  wgrad_dispatch(p, g, dtype, nullptr);
+  KD6D_CHECK_ARG(parts >= 1, "kd6d_conv2d_wgrad_parts: no kernel takes this geometry");
+  return parts;
+}
+
+extern "C" int kd6d_conv2d_wgrad(const kd6d_conv_geom* g, int dtype, const void* x, const void* dy,
+                                 float* dw_slab, int64_t slab_floats, int64_t* dbias, int64_t acc_hi_stride,
+                                 int cu_budget, void* stream) {
+  WgradParams p;
+  int rc = wgrad_params(g, dtype, cu_budget, "kd6d_conv2d_wgrad", p);
+  if (rc) return rc;
+  KD6D_CHECK_ARG(x && dy && dw_slab, "kd6d_conv2d_wgrad: null tensor pointer");
+  KD6D_CHECK_ARG(!dbias || acc_hi_stride != 0, "kd6d_conv2d_wgrad: acc_hi_stride = 0 with a bias accumulator");
+  p.x = x; p.dy = dy;
+  p.dw = dw_slab; p.slab_floats = (long long)slab_floats;
+  p.dbias = reinterpret_cast<long long*>(dbias); p.acc_hi = (long long)acc_hi_stride;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  g_wgrad_slab_short = false;
+  wgrad_dispatch(p, g, dtype, st);
+  KD6D_CHECK_ARG(!g_wgrad_slab_short, "kd6d_conv2d_wgrad: slab of %lld floats is too small (kd6d_conv2d_wgrad_parts x cout*k*k*cin)",
+                 (long long)slab_floats);
+  if (dtype != KD6D_BF16 && dbias) {           // exact-fp32 parity path: separate column-sum pass
+    rc = kd6d_detail::colsum_grad_planar(dtype, dy, p.M, g->cout, p.dbias, p.acc_hi, stream);
+    if (rc) return rc;
   }
   KD6D_CHECK_LAUNCH("kd6d_conv2d_wgrad");
   return KD6D_OK;

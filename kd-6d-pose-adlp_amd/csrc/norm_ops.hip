@@ -38,18 +38,20 @@ __device__ __forceinline__ float row_ror_add(float v) {
 
 // out[a]: `replicas` rows of C accumulators; this workgroup adds into row blockIdx.x % replicas (the rows are summed
 // by the consumer), so an address sees 1/replicas of the serially retired atomics.  E: KD6D_DET_ACT / KD6D_DET_GRAD.
-// Dynamic LDS: NACC * C accumulators (16 bytes each).
-// PLANAR: out[a] is the lo plane of a gradient-bucket accumulator array (hi words at + hi_off, no replica rows).
+// Inside the workgroup the threads that own the same channel meet through LDS SLOTS and a fixed-order fp32 sum -- no
+// LDS atomics: at most 16 partial sums per channel (narrow tensors: the lanes of a 16-lane row that own the same channel
+// granule are summed with DPP rotations first), one fixed-point conversion per channel and workgroup.
+// Dynamic LDS: kFlushLdsBytes.  PLANAR: out[a] is the lo plane of a gradient-bucket accumulator array (hi words at
+// + hi_off, no replica rows).
+constexpr int kFlushLdsBytes = 16384;      // 256 threads x NACC * EG (<= 16) floats
 template <int NACC, int EG, int E, bool PERFORMED = false, bool PLANAR = false>
 __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int C, int cg,
                                                     acc_t* const* out, int replicas = 1, long long hi_off = 0) {
-  extern __shared__ acc_t lds_acc[];  // NACC * C * {lo, hi}
-  for (int i = threadIdx.x; i < NACC * C * 2; i += kThreads) lds_acc[i] = 0;
-  __syncthreads();
-  // narrow tensors (C/EG < 16): the lanes of a 16-lane row that own the same channel granule are summed
-  // with DPP rotations first (a fixed order), so an LDS address sees 16 adds per workgroup instead of up to 256
+  extern __shared__ acc_t lds_acc[];
+  float* slot = reinterpret_cast<float*>(lds_acc);      // [partial][NACC * C]
   const int cgs = C / EG;
   const bool pre = cgs < 16 && (16 % cgs) == 0;
+  int part, nparts;
   if (pre) {
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
@@ -62,25 +64,59 @@ __device__ __forceinline__ void block_channel_flush(float (&acc)[NACC][EG], int 
         if (cgs <= 1) v = row_ror_add<1>(v);
         acc[a][e] = v;
       }
+    part = threadIdx.x >> 4;                // one partial per 16-lane row: lanes 0 .. cgs-1 of the row hold it
+    nparts = kThreads / 16;
+  } else {
+    part = threadIdx.x / cgs;               // thread t owns granule t % cgs (threads beyond (256 / cgs) * cgs idle)
+    nparts = kThreads / cgs;
   }
-  if (!pre || (int)(threadIdx.x & 15) < cgs) {
+  const int roff = replicas > 1 ? (int)(blockIdx.x % replicas) * C : 0;
+  if (nparts > 16) {
+    // odd channel counts (C / EG neither a divisor nor a multiple of 16, e.g. C = 40): up to 85 partials per channel --
+    // LDS fixed-point accumulators instead of slots
+    for (int i = threadIdx.x; i < NACC * C * 2; i += kThreads) lds_acc[i] = 0;
+    __syncthreads();
+    if (part < nparts) {
+#pragma unroll 1
+      for (int k = 0; k < NACC * EG; ++k) {
+        float v = 0.f;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+          for (int e = 0; e < EG; ++e) v = (k == a * EG + e) ? acc[a][e] : v;
+        det_add_lds<E>(&lds_acc[((k / EG) * C + cg * EG + (k % EG)) * 2], v);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
+      const int a = i / C, c = i - a * C;
+      if (!out[a]) continue;
+      if (PLANAR) det_add_words_planar(out[a] + c, hi_off, lds_acc[2 * i], lds_acc[2 * i + 1]);
+      else if (PERFORMED) det_add_words_performed(out[a] + (size_t)(roff + c) * 2, lds_acc[2 * i], lds_acc[2 * i + 1]);
+      else det_add_words(out[a] + (size_t)(roff + c) * 2, lds_acc[2 * i], lds_acc[2 * i + 1]);
+    }
+    return;
+  }
+  const bool writer = pre ? (int)(threadIdx.x & 15) < cgs : part < nparts;
+  if (writer) {
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int e = 0; e < EG; ++e) det_add_lds<E>(&lds_acc[(a * C + cg * EG + e) * 2], acc[a][e]);
+      for (int e = 0; e < EG; ++e) slot[(part * NACC + a) * C + cg * EG + e] = acc[a][e];
   }
   __syncthreads();
-  const int roff = replicas > 1 ? (int)(blockIdx.x % replicas) * C : 0;
   for (int i = threadIdx.x; i < NACC * C; i += kThreads) {
     const int a = i / C, c = i - a * C;
-    if (out[a]) {
-      if (PLANAR) {
-        det_add_words_planar(out[a] + c, hi_off, lds_acc[2 * i], lds_acc[2 * i + 1]);
-      } else {
-        acc_t* o = out[a] + (size_t)(roff + c) * 2;
-        if (PERFORMED) det_add_words_performed(o, lds_acc[2 * i], lds_acc[2 * i + 1]);
-        else det_add_words(o, lds_acc[2 * i], lds_acc[2 * i + 1]);
-      }
+    if (!out[a]) continue;
+    float t = slot[a * C + c];
+    for (int p = 1; p < nparts; ++p) t += slot[(p * NACC + a) * C + c];
+    const det_words w = kd6d_detail::det_split<E>(t);
+    if (PLANAR) {
+      det_add_words_planar(out[a] + c, hi_off, w.lo, w.hi);
+    } else {
+      acc_t* o = out[a] + (size_t)(roff + c) * 2;
+      if (PERFORMED) det_add_words_performed(o, w.lo, w.hi);
+      else det_add_words(o, w.lo, w.hi);
     }
   }
 }
@@ -1425,6 +1461,8 @@ long long gn_rows(const GnGeom& gm) {
 
 namespace kd6d_detail {
 int colsum_grad_planar(int dtype, const void* x, int64_t rows, int C, long long* acc, long long acc_hi, void* stream);
+int gn_stats_levels(int src_f32, const void* y, const int* row0, const int* hw, int nseg, int batch, int C, int G,
+                    unsigned mask, long long* stats, hipStream_t st);
 }
 
 #define DISPATCH_T(dtype, expr_bf16, expr_f32) \
@@ -1444,13 +1482,47 @@ extern "C" int kd6d_colstats(int dtype, const void* x, int64_t rows, int C, kd6d
   long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
   if (nb > kColstatsCap) nb = kColstatsCap;
   if (nb < 1) nb = 1;
-  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  const size_t lds = kFlushLdsBytes;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((int)nb), dim3(kThreads), lds, st,
                                 (const bf16_t*)x, (long long)rows, C, sum, sumsq, 0ll),
              hipLaunchKernelGGL(colstats_kernel<float>, dim3((int)nb), dim3(kThreads), lds, st,
                                 (const float*)x, (long long)rows, C, sum, sumsq, 0ll));
   KD6D_CHECK_LAUNCH("kd6d_colstats");
+  return KD6D_OK;
+}
+
+// conv_igemm.hip (stats_followup): the group statistics of the levels in `mask`, from the tensor the convolution stored.
+// Unmasked levels get no workgroups (their row-chunk count is 0); the statistics index keeps the level's own number.
+int kd6d_detail::gn_stats_levels(int src_f32, const void* y, const int* row0, const int* hw, int nseg, int batch, int C,
+                                 int G, unsigned mask, long long* stats, hipStream_t st) {
+  KD6D_CHECK_ARG(y && stats && nseg >= 1 && nseg <= KD6D_MAX_SEG && batch >= 1 && G >= 1 && G <= 64 && C % G == 0,
+                 "gn_stats_levels: bad arguments");
+  const int eg = src_f32 ? 4 : 8;
+  KD6D_CHECK_ARG(C % eg == 0 && (C / eg) <= 256 && 256 % (C / eg) == 0 && (C / G) * 2 >= eg, "gn_stats_levels: C=%d G=%d", C, G);
+  GnGeom gm;
+  gm.nseg = nseg; gm.batch = batch; gm.C = C; gm.G = G;
+  gm.chunk_rows = gn_chunk_rows();
+  gm.timeouts = nullptr;
+  int blk = 0;
+  for (int s = 0; s < KD6D_MAX_SEG; ++s) {
+    gm.row0[s] = s < nseg ? row0[s] : 0;
+    gm.hw[s] = s < nseg ? hw[s] : 0;
+    gm.blk0[s] = blk;
+    gm.cps[s] = 1;
+    if (s < nseg && ((mask >> s) & 1u)) {
+      gm.cps[s] = (hw[s] + gm.chunk_rows - 1) / gm.chunk_rows;
+      blk += batch * gm.cps[s];
+    }
+  }
+  gm.nblk = blk;
+  if (blk == 0) return KD6D_OK;
+  // gn_chunk() picks the LAST level whose first workgroup is <= the workgroup id: levels without workgroups share their
+  // first id with the next masked level and lose to it; trailing unmasked levels are moved out of range
+  for (int s = KD6D_MAX_SEG - 1; s >= 0 && !(s < nseg && ((mask >> s) & 1u)); --s) gm.blk0[s] = blk;
+  if (src_f32) hipLaunchKernelGGL((gn_stats_kernel<float, float>), dim3(blk), dim3(kThreads), 0, st, (const float*)y, gm, stats);
+  else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, bf16_t>), dim3(blk), dim3(kThreads), 0, st, (const bf16_t*)y, gm, stats);
+  KD6D_CHECK_LAUNCH("gn_stats_levels");
   return KD6D_OK;
 }
 
@@ -1465,7 +1537,7 @@ int kd6d_detail::colsum_grad_planar(int dtype, const void* x, int64_t rows, int 
   long long nb = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
   if (nb > kColstatsCap) nb = kColstatsCap;
   if (nb < 1) nb = 1;
-  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  const size_t lds = kFlushLdsBytes;
   acc_t* none = nullptr;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((colstats_kernel<bf16_t, true>), dim3((int)nb), dim3(kThreads), lds, st,
@@ -1526,7 +1598,7 @@ extern "C" int kd6d_bn_train_bwd_reduce(int dtype, int x_f32, const void* x, con
   long long nb = (ngran + kThreads * 8 - 1) / (kThreads * 8);
   if (nb > kBnBwdReduceCap) nb = kBnBwdReduceCap;
   if (nb < 1) nb = 1;
-  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  const size_t lds = kFlushLdsBytes;
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads), lds, st,
                                    (const TX_*)x, (const T_*)dz, ngran, C, mean, invstd, gamma, beta, act, sum_dy,
@@ -1593,7 +1665,7 @@ extern "C" int kd6d_bn_train_bwd(int dtype, int x_f32, const void* x, const void
   const float inv_rows = 1.f / (float)rows;
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((bn_bwd_onepass_kernel<T_, TX_>), dim3((int)nb), dim3(kThreads),
-                                  (size_t)2 * C * sizeof(kd6d_acc), st, (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, per,
+                                  (size_t)kFlushLdsBytes, st, (const TX_*)x, (const T_*)dz, (T_*)dx, ngran, per,
                                   C, inv_rows, mean, invstd, gamma, beta, act, sum_dy, sum_dy_xhat, counter, dgamma,
                                   dbeta, replicas, kd6d_ctx_timeouts_ptr()));
   KD6D_CHECK_LAUNCH("kd6d_bn_train_bwd");
@@ -1663,7 +1735,7 @@ extern "C" int kd6d_bn_pool_train_bwd(int dtype, int x_f32, const void* x, const
   if (nbr > kBnBwdReduceCap) nbr = kBnBwdReduceCap;
   if (nbr < 1) nbr = 1;
   const int nba = grid_for(items);
-  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  const size_t lds = kFlushLdsBytes;
   int cap = 0;
   DISPATCH_TTX(dtype, x_f32, cap = (bn_onepass_capacity<T_, TX_>(true)));
   cap = cap * 3 / 4;                                      // the whole grid must be resident for the barrier
@@ -1745,7 +1817,7 @@ extern "C" int kd6d_gn_relu_bwd(int dtype, int x_f32, const void* x, const void*
   const int eg = dtype == KD6D_BF16 ? 8 : 4;
   const long long ngran = gn_rows(gm) * (C / eg);
   const int nb = grid_for((ngran + 3) / 4);
-  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  const size_t lds = kFlushLdsBytes;
   KD6D_CHECK_ARG((C / groups) * 2 >= eg, "kd6d_gn_relu_bwd: C/groups=%d too small for %d-wide granules", C / groups, eg);
   if (!(flags & KD6D_GN_WS_ZEROED) &&
       hipMemsetAsync(gsum_ws, 0, sizeof(kd6d_acc) * 2 * (size_t)nseg * batch * groups, st) != hipSuccess) {
@@ -1836,7 +1908,7 @@ extern "C" int kd6d_gn_relu_bwd_pair(int dtype, int x_f32, const kd6d_gn_item* a
                        it[i]->beta, reinterpret_cast<acc_t*>(it[i]->gsum_ws), counters,
                        reinterpret_cast<acc_t*>(it[i]->dgamma), reinterpret_cast<acc_t*>(it[i]->dbeta)};
   }
-  const size_t lds = (size_t)2 * C * sizeof(kd6d_acc);
+  const size_t lds = kFlushLdsBytes;
   DISPATCH_TTX(dtype, x_f32,
                hipLaunchKernelGGL((gn_relu_bwd_onepass_pair_kernel<T_, TX_>), dim3(2 * g1.nblk), dim3(kThreads), lds, st,
                                   sets[0], sets[1], g1, eps, (long long)acc_hi_stride));

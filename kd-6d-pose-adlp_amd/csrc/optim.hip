@@ -82,20 +82,25 @@ __global__ __launch_bounds__(kT) void acc_read_kernel(long long* __restrict__ ac
   }
 }
 
-// End of the reverse sweep: the gradient bucket's PLANAR accumulators -> fp32 gradients, accumulators cleared for the
-// next step.  desc: int64 triples {first element, element count, first workgroup}; a workgroup owns 1024 elements.
+// End of the reverse sweep: every gradient that was summed across workgroups -> fp32 gradients, in one launch.
+// desc: int64 quintuples {first element, element count, first workgroup, parts, slab address}; a workgroup owns 1024
+// elements.  parts == 0: the elements' PLANAR fixed-point accumulators (cleared for the next step);
+// parts >= 1: the partial images of a per-layer weight gradient, slab[part][element], added in part order.
 __global__ __launch_bounds__(kT) void grad_acc_resolve_kernel(const long long* __restrict__ desc, int n_regions,
                                                               long long* __restrict__ acc, long long hi_off,
                                                               float* __restrict__ grads) {
   int r = 0;
   for (int i = 1; i < n_regions; ++i)
-    if ((long long)blockIdx.x >= desc[i * 3 + 2]) r = i;
-  const long long first = desc[r * 3], count = desc[r * 3 + 1];
-  const long long base = ((long long)blockIdx.x - desc[r * 3 + 2]) * 1024;
+    if ((long long)blockIdx.x >= desc[i * 5 + 2]) r = i;
+  const long long first = desc[r * 5], count = desc[r * 5 + 1];
+  const long long base = ((long long)blockIdx.x - desc[r * 5 + 2]) * 1024;
+  const int parts = (int)desc[r * 5 + 3];
+  const float* __restrict__ slab = reinterpret_cast<const float*>(desc[r * 5 + 4]);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const long long i = base + k * kT + threadIdx.x;
-    if (i < count) {
+    if (i >= count) continue;
+    if (parts == 0) {
       long long* lo = acc + first + i;
       const long long l = lo[0], h = lo[hi_off];
       if (l | h) {
@@ -103,6 +108,10 @@ __global__ __launch_bounds__(kT) void grad_acc_resolve_kernel(const long long* _
         lo[0] = 0;
         if (h) lo[hi_off] = 0;
       }
+    } else {
+      float t = slab[i];
+      for (int s2 = 1; s2 < parts; ++s2) t += slab[(size_t)s2 * count + i];
+      grads[first + i] += t;
     }
   }
 }
@@ -133,6 +142,7 @@ extern "C" int kd6d_grad_acc_resolve(const int64_t* desc_dev, int n_regions, int
                                      int64_t acc_hi_stride, float* grads, void* stream) {
   KD6D_CHECK_ARG(desc_dev && n_regions > 0 && total_blocks > 0 && acc && acc_hi_stride != 0 && grads,
                  "kd6d_grad_acc_resolve: bad arguments");
+  static_assert(KD6D_ACC_ACT == KD6D_DET_ACT && KD6D_ACC_GRAD == KD6D_DET_GRAD, "kd6d.h / kd6d_det.h classes");
   hipLaunchKernelGGL(grad_acc_resolve_kernel, dim3(total_blocks), dim3(kT), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const long long*>(desc_dev), n_regions, reinterpret_cast<long long*>(acc),
                      (long long)acc_hi_stride, grads);

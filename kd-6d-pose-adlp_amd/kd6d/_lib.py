@@ -106,7 +106,8 @@ SIGNATURES = {
     "kd6d_conv2d_fwd_norm_fusable": [_G, _I, _I, _I],
     "kd6d_conv2d_fwd_norm": [_G, _I, _P, _P, _P, _P, ctypes.POINTER(ConvNorm), _P],
     "kd6d_conv2d_dgrad": [_G, _I, _P, _P, _P, _I, _P],
-    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _P, _I64, _I, _P],
+    "kd6d_conv2d_wgrad": [_G, _I, _P, _P, _P, _I64, _P, _I64, _I, _P],
+    "kd6d_conv2d_wgrad_parts": [_G, _I, _I, _I],
     "kd6d_acc_read": [_P, _I64, _I, _P, _I, _I, _P],
     "kd6d_grad_acc_resolve": [_P, _I, _I, _P, _I64, _P, _P],
     "kd6d_wgrad_group_supported": [_G, _I],

@@ -38,7 +38,7 @@ def _pad8(c):
 # flat parameter store
 # ----------------------------------------------------------------------------------------
 class Entry:
-    __slots__ = ("name", "kind", "shape", "store_shape", "offset", "numel", "trainable", "region", "det")
+    __slots__ = ("name", "kind", "shape", "store_shape", "offset", "numel", "trainable", "region", "det", "slab", "parts")
 
     def __init__(self, name, kind, shape, store_shape, trainable):
         self.name, self.kind, self.shape, self.store_shape = name, kind, tuple(shape), tuple(store_shape)
@@ -47,6 +47,8 @@ class Entry:
         self.offset = -1
         self.region = None
         self.det = False        # its gradient is summed in the fixed-point accumulator image (ParamStore.gacc)
+        self.slab = None        # ... or arrives as partial images in this fp32 (parts, numel) slab (per-layer weight gradients)
+        self.parts = 0
 
 
 class ParamStore:
@@ -114,6 +116,8 @@ class ParamStore:
             self.grads = self.grads.to(device)
         if self.gacc is not None:
             self.gacc = self.gacc.to(device)
+        for e in self.order:
+            e.slab = None
         self._resolve_plans = {}
         if self.shadow is not None:
             self.shadow = self.shadow.to(device)
@@ -145,28 +149,48 @@ class ParamStore:
         b = self.base(e)
         return self.gacc[b:b + e.numel]
 
+    def slab(self, e, parts):
+        """fp32 (parts, numel) slab the per-layer weight-gradient launch of entry e stores its partial images into; marks
+        the entry for resolve_grads().  One slab per entry, kept for the life of the store (recorded graphs hold it)."""
+        assert e.region == "train" and not e.det
+        if e.slab is None or e.slab.shape[0] < parts:
+            assert not torch.cuda.is_current_stream_capturing(), "ParamStore.slab: allocation inside a graph capture"
+            e.slab = torch.empty(parts, e.numel, dtype=torch.float32, device=self.params.device)
+            e.parts = 0
+        if e.parts != parts:            # another geometry / budget than the last launch: the region table changes
+            assert not torch.cuda.is_current_stream_capturing(), \
+                "ParamStore.slab: a new split count inside a graph capture (run one eager warm-up step first)"
+            e.parts = parts
+            self._resolve_plans = {}
+        return e.slab[:parts]
+
     def resolve_grads(self, lo=0, hi=None):
-        """grads[lo:hi] += value of the accumulators of every marked entry in that range; accumulators cleared.  One
-        launch (kd6d_grad_acc_resolve); the region table is built on first use -- outside any stream capture."""
+        """grads[lo:hi] += the gradients that were summed across workgroups, for every marked entry in that range:
+        fixed-point accumulators (cleared) and partial-image slabs (added in part order).  One launch
+        (kd6d_grad_acc_resolve); the region table is built on first use -- outside any stream capture."""
         hi = self.n_train if hi is None else hi
         plan = self._resolve_plans.get((lo, hi))
         if plan is None:
             assert not torch.cuda.is_current_stream_capturing(), \
                 "ParamStore.resolve_grads: first use of a new set of accumulated gradients inside a graph capture " \
                 "(run one eager warm-up step first)"
-            regs = []
+            regs = []           # [first, count, parts, slab address]
             for e in self.order:
-                if e.region == "train" and e.det and lo <= self.base(e) < hi:
-                    b, n = self.base(e), e.numel
-                    if regs and regs[-1][0] + regs[-1][1] == b:
+                if e.region != "train" or not (lo <= self.base(e) < hi):
+                    continue
+                b, n = self.base(e), e.numel
+                if e.slab is not None and e.parts > 0:
+                    regs.append([b, n, e.parts, e.slab.data_ptr()])
+                elif e.det:
+                    if regs and regs[-1][2] == 0 and regs[-1][0] + regs[-1][1] == b:
                         regs[-1][1] += n
                     else:
-                        regs.append([b, n])
+                        regs.append([b, n, 0, 0])
             desc, blk = [], 0
-            for b, n in regs:
-                desc += [b, n, blk]
+            for b, n, parts, ptr in regs:
+                desc += [b, n, blk, parts, ptr]
                 blk += (n + 1023) // 1024
-            plan = (torch.tensor(desc or [0, 0, 0], dtype=torch.int64, device=self.params.device), len(regs), blk)
+            plan = (torch.tensor(desc or [0] * 5, dtype=torch.int64, device=self.params.device), len(regs), blk)
             self._resolve_plans[(lo, hi)] = plan
         desc, n_regions, blocks = plan
         if n_regions == 0:
@@ -200,6 +224,7 @@ class Conv:
         self.b = st.add(name + ".bias", "vec", (cout,), (self.cout_p,), trainable) if bias else None
         self.geoms = {}
         self._fusable = {}
+        self._parts = {}
         self.wt_off = None     # offset inside the dgrad-packed weight buffer
         net.convs.append(self)
 
@@ -256,6 +281,14 @@ class Conv:
         return ops.conv2d_fwd_norm(g, x, self.weight(), y, kind, gamma, beta, stats, counters, act, raw_out=raw_out,
                                    bias=self.bias(), groups=groups, flops=self.flops(g), **bn), g
 
+    def wgrad_slab(self, g, dtype, cu_budget):
+        """The slab this layer's weight-gradient launch stores its partial images into (ParamStore.slab)."""
+        key = (id(g), dtype, cu_budget, ops.get_option("wgrad.small"))
+        parts = self._parts.get(key)
+        if parts is None:
+            parts = self._parts[key] = ops.conv2d_wgrad_parts(g, dtype, self.b is not None, cu_budget)
+        return self.net.store.slab(self.w, parts)
+
     def bwd(self, x, dy, batch, levels, need_dx=True, dx=None, accumulate=False, need_dw=True):
         """wgrad (+ bias grad) into the flat grad buffer, then dgrad."""
         st = self.net.store
@@ -269,16 +302,16 @@ class Conv:
             grp.add(g, x, dy, st.storage(self.w, "grads"), None if self.b is None else st.storage(self.b, "grads"),
                     flops=self.flops(g))
         elif (side := self.net.next_side_stream()) is None:
-            ops.conv2d_wgrad(g, x, dy, st.acc(self.w), st.acc_stride, flops=self.flops(g),
-                             dbias=None if self.b is None else st.acc(self.b))
+            ops.conv2d_wgrad(g, x, dy, self.wgrad_slab(g, x.dtype, 0), flops=self.flops(g),
+                             dbias=None if self.b is None else st.acc(self.b), acc_stride=st.acc_stride)
         else:
             # the weight gradient feeds nothing in the reverse sweep: fork it onto the side stream so it
             # overlaps the dgrad / normalisation chain (both under-fill 256 CUs at these layer sizes);
             # PoseNet.backward joins before the gradient exchange.  x and dy are per-layer buffers.
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ops.conv2d_wgrad(g, x, dy, st.acc(self.w), st.acc_stride, flops=self.flops(g),
-                                 dbias=None if self.b is None else st.acc(self.b),
+                ops.conv2d_wgrad(g, x, dy, self.wgrad_slab(g, x.dtype, self.net.wgrad_cu_budget), flops=self.flops(g),
+                                 dbias=None if self.b is None else st.acc(self.b), acc_stride=st.acc_stride,
                                  cu_budget=self.net.wgrad_cu_budget)
         if not need_dx:
             return None

@@ -247,27 +247,41 @@ def conv2d_dgrad(geom, dy, wt, dx=None, accumulate=False, flops=0):
     return dx
 
 
-def conv2d_wgrad(geom, x, dy, dw_acc, acc_stride, flops=0, dbias=None, cu_budget=0):
-    """dw_acc (and dbias): lo-plane views of PLANAR gradient accumulators (int64; the hi word of element i sits
-    acc_stride words behind its lo word: ParamStore.acc / planar_acc)."""
+def conv2d_wgrad_parts(geom, dtype, with_bias=False, cu_budget=0):
+    """Number of partial dW images kd6d_conv2d_wgrad writes for this geometry / budget (kd6d_conv2d_wgrad_parts)."""
+    n = int(lib.kd6d_conv2d_wgrad_parts(geom.ref, dt_code(dtype), int(with_bias), int(cu_budget)))
+    if n < 1:
+        check(n, "kd6d_conv2d_wgrad_parts")
+    return n
+
+
+def conv2d_wgrad(geom, x, dy, dw_slab, flops=0, dbias=None, acc_stride=0, cu_budget=0):
+    """dw_slab: fp32 (parts, cout*k*k*cin) -- every pixel split stores its partial dW image (conv2d_wgrad_parts of them);
+    the caller adds them in order (ParamStore.resolve_grads / kd6d_grad_acc_resolve).  dbias: lo-plane view of PLANAR
+    gradient accumulators (int64; the hi word of element i sits acc_stride words behind its lo word)."""
     assert x.shape == (geom.rows_in, geom.cin) and dy.shape == (geom.rows_out, geom.cout)
-    assert x.dtype == dy.dtype and dw_acc.dtype == torch.int64 and acc_stride > 0
-    assert dw_acc.numel() == geom.cout * geom.ksize * geom.ksize * geom.cin
+    assert x.dtype == dy.dtype and dw_slab.dtype == torch.float32 and dw_slab.is_contiguous()
+    assert dw_slab.numel() % (geom.cout * geom.ksize * geom.ksize * geom.cin) == 0
     with _Timed("conv_wgrad", flops, geom):
-        assert dbias is None or (dbias.dtype == torch.int64 and dbias.numel() >= geom.cout)
-        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw_acc), _ptr(dbias),
-                                    int(acc_stride), int(cu_budget), _stream()), "kd6d_conv2d_wgrad")
-    return dw_acc
+        assert dbias is None or (dbias.dtype == torch.int64 and dbias.numel() >= geom.cout and acc_stride > 0)
+        check(lib.kd6d_conv2d_wgrad(geom.ref, dt_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw_slab), dw_slab.numel(),
+                                    _ptr(dbias), int(acc_stride), int(cu_budget), _stream()), "kd6d_conv2d_wgrad")
+    return dw_slab
 
 
 def conv2d_wgrad_f32(geom, x, dy, with_bias=False, cu_budget=0):
-    """Stand-alone weight gradient -> fp32 tensors (dw, dbias | None): accumulators made, filled and converted here."""
+    """Stand-alone weight gradient -> fp32 tensors (dw, dbias | None): slab and bias accumulators made, filled and
+    reduced here (torch arithmetic on the device: tests and tools; the engine resolves with kd6d_grad_acc_resolve)."""
     nw = geom.cout * geom.ksize * geom.ksize * geom.cin
-    n = nw + (geom.cout if with_bias else 0)
-    acc = planar_acc(n, x.device)
-    conv2d_wgrad(geom, x, dy, acc[:nw], n, dbias=acc[nw:n] if with_bias else None, cu_budget=cu_budget)
-    v = planar_acc_value(acc)
-    return v[:nw], (v[nw:n] if with_bias else None)
+    parts = conv2d_wgrad_parts(geom, x.dtype, with_bias, cu_budget)
+    slab = torch.empty(parts, nw, dtype=torch.float32, device=x.device)
+    acc = planar_acc(geom.cout, x.device) if with_bias else None
+    conv2d_wgrad(geom, x, dy, slab, dbias=acc[:geom.cout] if with_bias else None, acc_stride=geom.cout,
+                 cu_budget=cu_budget)
+    dw = slab[0].clone()
+    for k in range(1, parts):              # the order kd6d_grad_acc_resolve adds them in
+        dw += slab[k]
+    return dw, (planar_acc_value(acc) if with_bias else None)
 
 
 def set_option(name, value):

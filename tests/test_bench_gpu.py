@@ -38,8 +38,8 @@ def test_bench_line_contract_default_launch_mode(gpu_device):
     assert rf["traffic"] is None or rf["traffic"] > 1e9
     cfg = d["config"]
     assert cfg["teacher_group"] == 3 and "workload" in cfg and "model" not in cfg
-    assert cfg["teacher_passes_in_timed_region"] == 3                 # ceil(7 / 3)
-    assert cfg["teacher_images_in_timed_region"] == 3 * 3 * 16 >= 7 * 16
+    assert cfg["teacher_passes_completed_in_timed_region"] == 3       # ceil(7 / 3): the region ends with a completed pass
+    assert cfg["teacher_segments_in_timed_region"] == 7 and cfg["teacher_images_in_timed_region"] == 7 * 16
 
 
 def test_bench_self_launch_reports_missing_gpus(gpu_device):

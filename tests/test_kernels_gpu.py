@@ -294,11 +294,9 @@ def test_conv_wgrad(gpu_device, dtype, case):
     xs = [round_to(torch.randn(B, Cin, h, w_, generator=g), dtype) for (h, w_) in levels]
     dys = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
     dev = gpu_device
-    ga = _GradAcc([Cout * k * k * Cin, Cout], dev)
-    ops.conv2d_wgrad(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), ga.views[0], ga.stride,
-                     dbias=ga.views[1])
+    dw, db = ops.conv2d_wgrad_f32(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), with_bias=True)
     torch.cuda.synchronize()
-    dw, db = ga.value(0).view(Cout, k, k, Cin), ga.value(1)
+    dw = dw.view(Cout, k, k, Cin)
     ref = torch.zeros(Cout, Cin, k, k)
     ref_b = torch.zeros(Cout, dtype=torch.float64)
     for x, dy in zip(xs, dys):
@@ -332,12 +330,9 @@ def test_conv_wgrad_small_layers(gpu_device, case):
     xs = [round_to(torch.randn(B, Cin, h, w_, generator=g), dtype) for (h, w_) in levels]
     dys = [round_to(torch.randn(B, Cout, h, w_, generator=g), dtype) for (h, w_) in geom.levels_out]
     dev = gpu_device
-    ga = _GradAcc([Cout * k * k * Cin], dev)
-    for budget in (0, 16):                                                           # the call accumulates
-        ops.conv2d_wgrad(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), ga.views[0], ga.stride,
-                         cu_budget=budget)
+    dw = sum(ops.conv2d_wgrad_f32(geom, pack_levels(xs, dtype).to(dev), pack_levels(dys, dtype).to(dev), cu_budget=budget)[0]
+             for budget in (0, 16)).view(Cout, k, k, Cin)
     torch.cuda.synchronize()
-    dw = ga.value(0).view(Cout, k, k, Cin)
     ref = torch.zeros(Cout, Cin, k, k)
     for x, dy in zip(xs, dys):
         ref += torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=1, padding=pad)

@@ -93,7 +93,7 @@ def main():
         y = torch.empty(geom.rows_out, cout, dtype=torch.bfloat16, device=dev)
         dx = torch.empty(geom.rows_in, cin, dtype=torch.bfloat16, device=dev)
         nw = cout * k * k * cin
-        dw = ops.planar_acc(nw, dev)          # planar gradient accumulators (kd6d.h)
+        dw = torch.empty(ops.conv2d_wgrad_parts(geom, x.dtype), nw, device=dev)          # partial dW images (kd6d.h)
         flop = 2.0 * geom.rows_out * cout * k * k * cin
         for kind in kinds:
             if name.startswith(("t.", "t640.")) and kind != "fwd":
@@ -109,7 +109,7 @@ def main():
             elif kind == "dgrad":
                 us = timeit(lambda: ops.conv2d_dgrad(geom, dy, w, dx=dx), a.iters)
             else:
-                us = timeit(lambda: ops.conv2d_wgrad(geom, x, dy, dw[:nw], nw), a.iters)
+                us = timeit(lambda: ops.conv2d_wgrad(geom, x, dy, dw), a.iters)
             print("| %s | %s | %d | %d | %d | %.2f | %.1f | %.0f |" % (name, kind, geom.rows_out, cout, k * k * cin,
                                                                       flop / 1e9, us, flop / max(us, 1e-9) / 1e6))
 
