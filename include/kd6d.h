@@ -88,16 +88,19 @@ int kd6d_abi_version(void);
  * `kind`; clear != 0 zeroes them afterwards.  kd6d_grad_acc_resolve: desc_dev holds n_regions int64 quintuples
  * {first element, element count, first workgroup, parts, slab address}, regions in ascending workgroup order,
  * total_blocks workgroups of 1024 elements each.  parts == 0: grads[e] += value(planar accumulator of element e, class
- * KD6D_ACC_GRAD), accumulator cleared.  parts >= 1: grads[first + i] += slab[0][i] + slab[1][i] + ... (that order),
- * slab = `parts` partial images of `count` floats each (what kd6d_conv2d_wgrad wrote). */
+ * KD6D_ACC_GRAD), accumulator cleared.  parts >= 1: grads[first + i] += the sum over the `parts` partial images
+ * slab[part][i] of `count` floats each (what kd6d_conv2d_wgrad wrote), in a fixed association: PG =
+ * kd6d_grad_acc_resolve_part_groups(parts) interleaved partial sums (parts g, g + PG, ... in order), then those in g
+ * order.  Workgroups per region: ceil(count / 1024) for parts == 0, ceil(count / (1024 / PG)) otherwise. */
 typedef struct kd6d_acc { int64_t lo, hi; } kd6d_acc;
-/* Workspace of a launch that reduces to ONE fp32 scalar (kd6d_focal_fwd, kd6d_student_points' loss_reg, kd6d_sumsq):
+/* Workspace of a launch that reduces to ONE fp32 scalar (kd6d_focal_fwd, kd6d_student_points' loss_reg):
  * 32 bytes, pre-zeroed; the launch's LAST workgroup converts the fixed-point total and WRITES the scalar (the running
  * total if the workspace is reused without zeroing -- the "+=" of earlier ABI versions); arrivals is left at 0. */
 typedef struct kd6d_scalar_ws { int64_t lo, hi; uint32_t arrivals; uint32_t reserved[3]; } kd6d_scalar_ws;
 #define KD6D_ACC_ACT 32
 #define KD6D_ACC_GRAD 52
 int kd6d_acc_read(kd6d_acc* acc, int64_t n, int kind, float* out, int accumulate, int clear, void* stream);
+int kd6d_grad_acc_resolve_part_groups(int parts);
 int kd6d_grad_acc_resolve(const int64_t* desc_dev, int n_regions, int total_blocks, int64_t* acc,
                           int64_t acc_hi_stride, float* grads, void* stream);
 
@@ -526,19 +529,21 @@ int kd6d_dzi_crop(const uint8_t* frames_bgr, const float* masks, int B, int H, i
                   float* bbox_scale, void* stream);
 
 /* ---- optimiser: replaces clip_grad_norm_ + AdamW.step of train_kd.py:138-139 on one flat buffer.
- * kd6d_sumsq writes sum(x^2) to *out through ws (kd6d_scalar_ws, pre-zeroed: reproducible); kd6d_clip_adamw applies
- * g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) then the decoupled-weight-decay Adam update
+ * kd6d_sumsq writes KD6D_SUMSQ_PARTS partial sums of x^2 (one per workgroup, unused slots zeroed; no atomics);
+ * kd6d_clip_adamw adds them in a fixed order (reproducible), writes the total to *gnorm_sq_out (optional) and applies
+ * g *= min(1, max_norm/(sqrt(total)+1e-6)) (gnorm_partials == NULL: no clipping) then the decoupled-weight-decay Adam update
  * (torch.optim.AdamW semantics, step counted from 1) and refreshes the bf16 shadow if given.
- * hyper_dev (optional, 16 floats on the device, 16-byte aligned: lr, 1-beta1^t, sqrt(1-beta2^t), a fourth that
- * kd6d_set_hyper sets to 0 -- the host keeps the squared gradient norm there -- and, at floats 8..15, the kd6d_scalar_ws
- * of kd6d_sumsq, cleared by kd6d_set_hyper as well: no launch of its own) overrides lr/step:
+ * hyper_dev (optional, 4 floats on the device: lr, 1-beta1^t, sqrt(1-beta2^t), and a fourth that kd6d_set_hyper
+ * sets to 0 -- the host passes it as gnorm_sq_out) overrides lr/step:
  * it lets the launch sit inside a captured hipGraph while the OneCycle schedule of
  * libs/train_libs.py:120 keeps advancing on the host; kd6d_set_hyper writes it (values travel in
  * the kernel arguments, so the host may run ahead of the device). */
-int kd6d_sumsq(const float* x, int64_t n, float* out, kd6d_scalar_ws* ws, void* stream);
+#define KD6D_SUMSQ_PARTS 128
+int kd6d_sumsq(const float* x, int64_t n, float* partials, void* stream);
 int kd6d_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                    const float* gnorm_sq, double max_norm, double lr, double beta1, double beta2, double eps,
-                    double weight_decay, int64_t step, const float* hyper_dev, void* bf16_shadow, void* stream);
+                    const float* gnorm_partials, float* gnorm_sq_out, double max_norm, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int64_t step, const float* hyper_dev,
+                    void* bf16_shadow, void* stream);
 int kd6d_set_hyper(float* hyper_dev, double lr, double beta1, double beta2, int64_t step, void* stream);
 int kd6d_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 

@@ -1,8 +1,13 @@
 """Build libkd6d.so (gfx950 only) in-tree with hipcc.
 
-Usage: python build.py [--force]
+Usage: python build.py [--force] [--sanitize]
 The shared object lands next to the sources (csrc/libkd6d.so); it is git-ignored but
 travels to the GPU box with the gpurun snapshot.
+
+--sanitize builds csrc/libkd6d_san.so instead: the HOST code of every csrc/*.hip -- launchers, dispatch rules,
+work-list planners, argument checks -- under AddressSanitizer + UndefinedBehaviorSanitizer (-O1; the device code is
+compiled as usual: sanitizers are not available for gfx950 code objects on this pool).  tests/test_sanitize_host.py drives
+it on the CPU through tests/san_driver.cpp (argument checks, dry-run dispatch, split and work-list planning).
 """
 import hashlib
 import os
@@ -48,10 +53,25 @@ def _source_digest(src, base):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g1", "-Wno-option-ignored"]
+
+
+def build(force=False, verbose=True, sanitize=False):
     """Compile every csrc/*.hip whose source, the shared headers or the flags changed since its object was built
     (one stamp per object), then link.  Returns the path of the shared object."""
-    objdir = os.path.join(CSRC, "build")
+    global FLAGS, OUT
+    flags0, out0 = FLAGS, OUT
+    if sanitize:
+        FLAGS = [f for f in FLAGS if f != "-O3"] + ["-O1"] + SAN_FLAGS
+        OUT = os.path.join(CSRC, "libkd6d_san.so")
+    try:
+        return _build(force, verbose, "build_san" if sanitize else "build", SAN_FLAGS if sanitize else [])
+    finally:
+        FLAGS, OUT = flags0, out0
+
+
+def _build(force, verbose, objsub, link_extra):
+    objdir = os.path.join(CSRC, objsub)
     os.makedirs(objdir, exist_ok=True)
     base = _headers_digest()
     srcs = _sources()
@@ -66,7 +86,7 @@ def build(force=False, verbose=True):
             return f.read().strip() != digests[src]
 
     todo = [s for s in srcs if stale(s)]
-    link_stamp = os.path.join(CSRC, ".build_stamp")
+    link_stamp = os.path.join(CSRC, ".build_stamp" if objsub == "build" else "." + objsub + "_stamp")
     all_dig = hashlib.sha256("".join(digests[s] for s in srcs).encode()).hexdigest()
     if not todo and os.path.exists(OUT) and os.path.exists(link_stamp):
         with open(link_stamp) as f:
@@ -88,7 +108,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
         list(ex.map(compile_one, todo))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + link_extra + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
@@ -98,4 +118,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv))

@@ -110,6 +110,7 @@ SIGNATURES = {
     "kd6d_conv2d_wgrad_parts": [_G, _I, _I, _I],
     "kd6d_acc_read": [_P, _I64, _I, _P, _I, _I, _P],
     "kd6d_grad_acc_resolve": [_P, _I, _I, _P, _I64, _P, _P],
+    "kd6d_grad_acc_resolve_part_groups": [_I],
     "kd6d_wgrad_group_supported": [_G, _I],
     "kd6d_wgrad_group_plan": [ctypes.POINTER(WgradItem), _I, _I, _I, _P, _I64, ctypes.POINTER(ctypes.c_int32)],
     "kd6d_wgrad_group_launch": [_P, _I, _I, _P, _P],
@@ -152,8 +153,8 @@ SIGNATURES = {
     "kd6d_loss_backward": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _I, _I,
                            _P, _P, _P],
     "kd6d_dzi_crop": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P],
-    "kd6d_sumsq": [_P, _I64, _P, _P, _P],
-    "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
+    "kd6d_sumsq": [_P, _I64, _P, _P],
+    "kd6d_clip_adamw": [_P, _P, _P, _P, _I64, _P, _P, _D, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
     "kd6d_set_hyper": [_P, _D, _D, _D, _I64, _P],
     "kd6d_cast_f32_to_bf16": [_P, _P, _I64, _P],
     "kd6d_comm_unique_id": [_P],

@@ -189,7 +189,8 @@ class ParamStore:
             desc, blk = [], 0
             for b, n, parts, ptr in regs:
                 desc += [b, n, blk, parts, ptr]
-                blk += (n + 1023) // 1024
+                per = 1024 // (ops.lib.kd6d_grad_acc_resolve_part_groups(parts) if parts else 1)     # elements per workgroup
+                blk += (n + per - 1) // per
             plan = (torch.tensor(desc or [0] * 5, dtype=torch.int64, device=self.params.device), len(regs), blk)
             self._resolve_plans[(lo, hi)] = plan
         desc, n_regions, blocks = plan

@@ -20,12 +20,12 @@ class FusedClipAdamW(torch.optim.Optimizer):
         dev = st.params.device
         self.exp_avg = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(st.n_train, dtype=torch.float32, device=dev)
-        # lr, 1-b1^t, sqrt(1-b2^t) in graph-replay form, the squared gradient norm, and (floats 8..15) the fixed-point
-        # workspace kd6d_sumsq sums it in (kd6d_scalar_ws: reproducible): kd6d_set_hyper (advance(), before every
-        # launch) writes the three and clears the rest in one launch
-        self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
+        # lr, 1-b1^t, sqrt(1-b2^t) in graph-replay form and the squared gradient norm (written by kd6d_clip_adamw from
+        # kd6d_sumsq's partial sums, added in a fixed order: reproducible); kd6d_set_hyper (advance(), before every launch)
+        # writes the three and clears the fourth in one launch
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
         self.gnorm_sq = self.hyper[3:4]
-        self.gnorm_ws = self.hyper[8:16]
+        self.gnorm_parts = torch.zeros(128, dtype=torch.float32, device=dev)        # KD6D_SUMSQ_PARTS
         self.steps = 0
 
     @torch.no_grad()
@@ -51,10 +51,10 @@ class FusedClipAdamW(torch.optim.Optimizer):
         n = st.n_train
         P = ops._ptr
         s = ops._stream()
-        check(lib.kd6d_sumsq(P(st.grads), n, P(self.gnorm_sq), P(self.gnorm_ws), s), "kd6d_sumsq")
+        check(lib.kd6d_sumsq(P(st.grads), n, P(self.gnorm_parts), s), "kd6d_sumsq")
         shadow = st.ensure_shadow() if self.net.dtype == torch.bfloat16 else None
-        check(lib.kd6d_clip_adamw(P(st.params), P(st.grads), P(self.exp_avg), P(self.exp_avg_sq), n, P(self.gnorm_sq),
-                                  float(self.max_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+        check(lib.kd6d_clip_adamw(P(st.params), P(st.grads), P(self.exp_avg), P(self.exp_avg_sq), n, P(self.gnorm_parts),
+                                  P(self.gnorm_sq), float(self.max_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                   float(g["eps"]), float(g["weight_decay"]), max(self.steps, 1),
                                   P(self.hyper) if device_schedule else None, P(shadow), s), "kd6d_clip_adamw")
         self.net._weights_dirty = shadow is None and self.net.dtype == torch.bfloat16

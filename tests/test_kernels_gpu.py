@@ -977,15 +977,15 @@ def test_fused_clip_adamw_matches_torch(gpu_device):
         opt.step(); sch.step()
         gd = grad.to(dev)
         ss = torch.zeros(1, device=dev)
-        ss_ws = torch.zeros(8, device=dev)               # kd6d_scalar_ws
-        ops.check(lib.kd6d_sumsq(P(gd), n, P(ss), P(ss_ws), ops._stream()))
+        parts = torch.empty(128, device=dev)             # KD6D_SUMSQ_PARTS partial sums, added by kd6d_clip_adamw
+        ops.check(lib.kd6d_sumsq(P(gd), n, P(parts), ops._stream()))
         if step % 2:       # host-scalar form
-            ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(ss), 1.0, lr, 0.9, 0.999, 1e-8, 1e-4, step,
+            ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(parts), P(ss), 1.0, lr, 0.9, 0.999, 1e-8, 1e-4, step,
                                           None, P(shadow), ops._stream()))
         else:              # device-resident schedule (the hipGraph replay form); host lr/step args are ignored
-            hyper = torch.zeros(16, device=dev)
+            hyper = torch.zeros(4, device=dev)
             ops.check(lib.kd6d_set_hyper(P(hyper), lr, 0.9, 0.999, step, ops._stream()))
-            ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(ss), 1.0, 123.0, 0.9, 0.999, 1e-8, 1e-4, 0,
+            ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), n, P(parts), P(ss), 1.0, 123.0, 0.9, 0.999, 1e-8, 1e-4, 0,
                                           P(hyper), P(shadow), ops._stream()))
         torch.cuda.synchronize()
         assert float(ss) == pytest.approx(float((grad.double() ** 2).sum()), rel=1e-5)
@@ -996,7 +996,7 @@ def test_fused_clip_adamw_matches_torch(gpu_device):
     g = torch.Generator().manual_seed(1)
     for it in range(3):
         gd = torch.randn(16, generator=g).to(dev)
-        ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), 16, None, 0.0, float(z["lrs"][it]), 0.9, 0.999, 1e-8,
+        ops.check(lib.kd6d_clip_adamw(P(p), P(gd), P(m), P(v), 16, None, None, 0.0, float(z["lrs"][it]), 0.9, 0.999, 1e-8,
                                       1e-4, it + 1, None, None, ops._stream()))
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), z["params"][it], rtol=1e-5, atol=1e-7)
@@ -1131,7 +1131,14 @@ def test_conv_fwd_norm_group(gpu_device, dtype, case):
     bias = torch.randn(C, generator=gen) * 0.1
     gamma = torch.rand(C, generator=gen) + 0.5
     beta = torch.randn(C, generator=gen) * 0.2
-    assert ops.conv_norm_fusable(geom, dtype, ops.NORM_GROUP, G)
+    # a level whose rows do not fall into whole 16-row fragments of one image (H*W or its first row not a multiple of 16)
+    # gets its statistics from a follow-up launch behind the convolution: nothing to wait for inside the kernel, so such
+    # geometries do not take the fused launch (round 4) -- the two-launch path below is then checked against torch alone
+    row, whole = 0, True
+    for (h, w_) in levels:
+        whole = whole and (h * w_) % 16 == 0 and row % 16 == 0
+        row += B * h * w_
+    assert bool(ops.conv_norm_fusable(geom, dtype, ops.NORM_GROUP, G)) == whole
     xp = pack_levels(xs, dtype).to(dev)
     wk = w_to_krsc(w, dtype).to(dev)
     raws, ys = [], []
@@ -1141,7 +1148,8 @@ def test_conv_fwd_norm_group(gpu_device, dtype, case):
         ys.append(F.relu(F.group_norm(raw, G, gamma.double(), beta.double(), 1e-5)))
     y = torch.empty(geom.rows_out, C, dtype=dtype, device=dev)
     raw_out = torch.empty(geom.rows_out, C, dtype=torch.float32, device=dev)
-    for with_raw in (True, False):          # eval-mode callers do not store the pre-normalisation tensor
+    stats = None
+    for with_raw in ((True, False) if whole else ()):          # eval-mode callers do not store the pre-normalisation tensor
         stats = torch.zeros(ops.conv_norm_stats_floats(geom, ops.NORM_GROUP, G), device=dev)
         ctr = torch.zeros(ops.conv_norm_counter_words(geom, ops.NORM_GROUP), dtype=torch.int32, device=dev)
         y.fill_(7.0)
@@ -1151,16 +1159,21 @@ def test_conv_fwd_norm_group(gpu_device, dtype, case):
         assert ops.lib.kd6d_barrier_timeouts() == 0
         for gl, ref in zip(unpack_levels(y.float().cpu(), B, levels), ys):
             torch.testing.assert_close(gl.double(), ref, **_tol(dtype, stored=True))
-    for gl, ref in zip(unpack_levels(raw_out.cpu(), B, levels), raws):
-        torch.testing.assert_close(gl.double(), ref, rtol=2e-4, atol=2e-4)
+    if whole:
+        for gl, ref in zip(unpack_levels(raw_out.cpu(), B, levels), raws):
+            torch.testing.assert_close(gl.double(), ref, rtol=2e-4, atol=2e-4)
     # the two-launch path on the same inputs
-    stats2 = torch.zeros_like(stats)
+    n_st = len(levels) * B * G * 2
+    stats2 = _accs(n_st, dev)
     raw2 = ops.conv2d_fwd(geom, xp, wk, ch_shift=bias.to(dev), out_f32=True, stats=stats2, stats_groups=G)
     y2 = torch.empty_like(y)
     ops.gn_relu_fwd(raw2, y2, [h * w_ for (h, w_) in levels], B, G, gamma.to(dev), beta.to(dev), 1e-5, stats2,
                     flags=ops.GN_STATS_READY)
     torch.cuda.synchronize()
-    n_st = len(levels) * B * G * 2
+    for gl, ref in zip(unpack_levels(y2.float().cpu(), B, levels), ys):
+        torch.testing.assert_close(gl.double(), ref, **_tol(dtype, stored=True))
+    if not whole:
+        return
     torch.testing.assert_close(_acc_val(stats, n_st).cpu(), _acc_val(stats2, n_st).cpu(), rtol=1e-6, atol=1e-5)   # what kd6d_gn_relu_bwd reads
     d = (y.float() - y2.float()).abs()
     ulp = y2.float().abs() * 2.0 ** -7 + 1e-6 if dtype == torch.bfloat16 else y2.float().abs() * 1e-5 + 1e-5

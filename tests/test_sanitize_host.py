@@ -1,0 +1,30 @@
+"""CPU: the host code of csrc/*.hip under AddressSanitizer + UndefinedBehaviorSanitizer.
+
+`python kd-6d-pose-adlp_amd/build.py --sanitize` builds csrc/libkd6d_san.so (about five minutes: the device code is
+compiled as usual; the test SKIPS until it exists -- the default CPU suite must stay within minutes); tests/san_driver.cpp
+drives the entry points that work on the host -- argument checks of every family, the dry-run dispatch behind
+kd6d_conv2d_fwd_norm_fusable, the split planning behind kd6d_conv2d_wgrad_parts, the grouped weight gradient's work-list
+planner -- none of which launches a kernel.  Any sanitizer report fails the test."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = os.path.join(ROOT, "kd-6d-pose-adlp_amd", "csrc", "libkd6d_san.so")
+
+
+def test_host_code_under_asan_ubsan(tmp_path):
+    if not os.path.exists(SAN):
+        pytest.skip("csrc/libkd6d_san.so not built: python kd-6d-pose-adlp_amd/build.py --sanitize")
+    exe = str(tmp_path / "san_driver")
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-g1", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           "-Wno-option-ignored", "-Wno-unused-value", "-o", exe, os.path.join(ROOT, "tests", "san_driver.cpp"), SAN,
+           "-Wl,-rpath," + os.path.dirname(SAN)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
+    assert r.returncode == 0 and "SAN_DRIVER_OK" in r.stdout, out[-4000:]
