@@ -98,13 +98,13 @@ __global__ __launch_bounds__(kT) void acc_read_kernel(long long* __restrict__ ac
 // desc: int64 quintuples {first element, element count, first workgroup, parts, slab address}.
 //   parts == 0: the elements' PLANAR fixed-point accumulators (cleared for the next step); 1024 elements per workgroup.
 //   parts >= 1: the partial images of a per-layer weight gradient, slab[part][element].  A workgroup owns 1024 / PG
-//   elements, PG = kd6d_resolve_part_groups(parts) threads per element: thread (element, g) adds parts g, g + PG, ... in
-//   that order, the PG partial sums meet in LDS and are added in g order -- a FIXED association (bitwise reproducible),
-//   with at most 32 dependent loads per thread (a narrow layer split 512 ways summed by one thread per element took
-//   0.5 ms: 512 exposed memory round trips).
+//   elements, PG = kd6d_resolve_part_groups(parts) threads per element: thread (element, g) adds parts g, g + PG, ... into
+//   four interleaved running sums (four loads in flight), the PG partial sums meet in LDS and are added in g order -- a
+//   FIXED association (bitwise reproducible) with at most 4 dependent memory round trips per thread (a narrow layer split
+//   512 ways summed by one thread per element took 0.5 ms: 512 exposed round trips; 32 in a row still 60 us).
 __host__ __device__ inline int resolve_part_groups(int parts) {
   int pg = 1;
-  while (pg < 16 && parts > 32 * pg) pg *= 2;
+  while (pg < 32 && parts > 16 * pg) pg *= 2;
   return pg;
 }
 
@@ -142,10 +142,17 @@ __global__ __launch_bounds__(kT) void grad_acc_resolve_kernel(const long long* _
     const int slot = k * kT + threadIdx.x;                 // (g, j): consecutive threads -> consecutive elements
     const int g = slot / epb, j = slot - g * epb;
     const long long i = base + j;
-    float t = 0.f;
-    if (i < count)
-      for (int s2 = g; s2 < parts; s2 += pg) t += slab[(size_t)s2 * count + i];
-    part_sum[slot] = t;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (i < count) {
+      for (int s2 = g; s2 < parts; s2 += 4 * pg) {
+        const float a0 = slab[(size_t)s2 * count + i];
+        const float a1 = s2 + pg < parts ? slab[(size_t)(s2 + pg) * count + i] : 0.f;
+        const float a2 = s2 + 2 * pg < parts ? slab[(size_t)(s2 + 2 * pg) * count + i] : 0.f;
+        const float a3 = s2 + 3 * pg < parts ? slab[(size_t)(s2 + 3 * pg) * count + i] : 0.f;
+        t0 += a0; t1 += a1; t2 += a2; t3 += a3;
+      }
+    }
+    part_sum[slot] = (t0 + t1) + (t2 + t3);
   }
   __syncthreads();
   for (int j = threadIdx.x; j < epb; j += kT) {

@@ -18,9 +18,10 @@ def test_host_code_under_asan_ubsan(tmp_path):
     if not os.path.exists(SAN):
         pytest.skip("csrc/libkd6d_san.so not built: python kd-6d-pose-adlp_amd/build.py --sanitize")
     exe = str(tmp_path / "san_driver")
-    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-g1", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
-           "-Wno-option-ignored", "-Wno-unused-value", "-o", exe, os.path.join(ROOT, "tests", "san_driver.cpp"), SAN,
-           "-Wl,-rpath," + os.path.dirname(SAN)]
+    # the driver is plain C++ (no kernels): the same clang that built the library, the same sanitizer runtime
+    cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-O1", "-g1", "-std=c++17", "-fsanitize=address,undefined",
+           "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "san_driver.cpp"),
+           "-L" + os.path.dirname(SAN), "-lkd6d_san", "-Wl,-rpath," + os.path.dirname(SAN), "-Wl,--allow-shlib-undefined"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
