@@ -5,9 +5,9 @@
 // What crosses workgroups is exchanged ONLY through device-scope atomics (partial sums, counters) and device-scope
 // atomic loads afterwards: those are performed at the memory side, beyond the per-XCD L2s, so no L2 write-back /
 // invalidate (what an agent-scope release / acquire fence costs on a multi-XCD part, for every workgroup) is needed.
-// Partial sums are published with atomic_add_performed (a RETURNING atomic: its result can only come back from where
-// the add was performed, so the add is visible before the workgroup arrives; with returnless atomics one step in ~20
-// came out wrong); the workgroup-scope release and the __syncthreads order the arrival behind them.
+// Partial sums are published with det_add_performed (kd6d_det.h; a RETURNING integer atomic: its result can only come
+// back from where the add was performed, so the add is visible before the workgroup arrives; with returnless atomics one
+// step in ~20 came out wrong); the workgroup-scope release and the __syncthreads order the arrival behind them.
 //
 // Every spin is bounded (~0.3 s): a barrier that cannot complete gives up, counts itself in the caller's timeout
 // counter (kd6d_barrier_timeouts()) and lets the kernel drain -- wrong numbers instead of a hung GPU.
@@ -35,12 +35,6 @@ namespace kd6d_detail {
 
 constexpr unsigned kSpinLimit = 1u << 21;
 constexpr unsigned kBarrierFan = 16;      // sub-counters of a grid barrier (KD6D_BARRIER_WORDS = 32 words per barrier)
-
-// Device-scope float add whose RESULT the thread waits for.
-__device__ __forceinline__ void atomic_add_performed(float* p, float v) {
-  const float r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("" ::"v"(r));
-}
 
 __device__ __forceinline__ float load_device_scope(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

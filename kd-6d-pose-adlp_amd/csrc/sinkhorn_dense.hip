@@ -707,7 +707,7 @@ template <int D>
 __global__ __launch_bounds__(256) void dense_finalize_kernel(
     const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ pot, int N, int M,
     float eps, float lam, float rho, const float* __restrict__ grad_xx, const float* __restrict__ grad_xy,
-    float* __restrict__ loss, float* __restrict__ gx_out, float* __restrict__ galpha_out) {
+    float* __restrict__ loss_parts, float* __restrict__ gx_out, float* __restrict__ galpha_out) {
   __shared__ float s_part[4];
   const bool unb = rho > 0.f;
   const float w_unb = rho + 0.5f * eps, inv_rho = unb ? 1.f / rho : 0.f;
@@ -740,7 +740,16 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(
   part = wave_sum(part);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  // one partial per workgroup, added in block order by dense_loss_sum_kernel: the value does not depend on the order
+  // in which the workgroups retire (include/kd6d.h, "reproducible reductions")
+  if (threadIdx.x == 0) loss_parts[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+__global__ __launch_bounds__(64) void dense_loss_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ loss) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += parts[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) *loss = s;
 }
 
 // coordinate-wise min / max over all points of both sets -> box diagonal (geomloss max_diameter)
@@ -870,11 +879,12 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   }
   launch(2, eps, true);
   const float lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return KD6D_ERR_LAUNCH;
   int nb = (nmax + 255) / 256;
   if (nb > 512) nb = 512;
+  // the other potential buffer (2 (N + M) floats >= nb) is free after the last pass: it takes the per-workgroup partials
   hipLaunchKernelGGL(dense_finalize_kernel<D>, dim3(nb), dim3(256), 0, st, alpha, beta, cur, N, M, (float)eps, lam,
-                     (float)rho, gxx, gxy, loss, gx, galpha);
+                     (float)rho, gxx, gxy, nxt, gx, galpha);
+  hipLaunchKernelGGL(dense_loss_sum_kernel, dim3(1), dim3(64), 0, st, (const float*)nxt, nb, loss);
   return KD6D_OK;
 }
 
@@ -938,7 +948,7 @@ extern "C" int kd6d_sinkhorn_dense_fwd_bwd(const float* x, const float* alpha, c
       kd6d_set_error("kd6d_sinkhorn_dense_fwd_bwd: D=%d (supported: 2, 4, 8, 16)", D);
       return KD6D_ERR_UNSUPPORTED;
   }
-  if (rc) { kd6d_set_error("kd6d_sinkhorn_dense_fwd_bwd: memset failed"); return rc; }
+  if (rc) { kd6d_set_error("kd6d_sinkhorn_dense_fwd_bwd: launch failed"); return rc; }
   KD6D_CHECK_LAUNCH("kd6d_sinkhorn_dense_fwd_bwd");
   return KD6D_OK;
 }

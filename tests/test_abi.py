@@ -78,3 +78,25 @@ def test_kernel_selection_options_table():
                 src = open(os.path.join(d, f)).read()
                 assert "getenv(" not in src, f
                 assert not re.search(r"environ[^\n]*KD6D_", src), f
+
+
+def test_no_float_atomics_in_the_product_sources():
+    """Every cross-workgroup sum of the path is order-independent (include/kd6d.h, "reproducible reductions"): the
+    sources hold no floating-point atomic -- integer atomics on fixed-point images (kd6d_det.h), ordered partials
+    and slabs instead.  A float atomic slipping back in would make two executions of a step differ in the last bits."""
+    csrc = os.path.join(ROOT, "kd-6d-pose-adlp_amd", "csrc")
+    allowed_int = re.compile(r"atomicAdd\s*\(\s*(timeouts|reinterpret_cast<unsigned long long\*>)")
+    offenders = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        for no, line in enumerate(open(os.path.join(csrc, name)), 1):
+            code = line.split("//")[0]
+            if "atomicAdd" in code and not allowed_int.search(code):
+                offenders.append(f"{name}:{no}: {line.strip()}")
+            if "unsafeAtomicAdd" in code or "atomicAdd_system" in code:
+                offenders.append(f"{name}:{no}: {line.strip()}")
+            m = re.search(r"__hip_atomic_fetch_add\s*\(([^,]+),", code)
+            if m and re.search(r"float|double", code):
+                offenders.append(f"{name}:{no}: {line.strip()}")
+    assert not offenders, "\n".join(offenders)

@@ -907,6 +907,9 @@ def test_sinkhorn_dense_kernel_vs_oracle(gpu_device, case):
     loss2, _, _ = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach,
                                      diameter=max_diameter(x[None], y[None]))
     assert float(loss2) == pytest.approx(float(loss), rel=1e-5)
+    # a second execution is bitwise equal: per-workgroup partials are added in block order, no float atomics
+    loss3, gx3, ga3 = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach)
+    assert torch.equal(loss3, loss) and torch.equal(gx3, gx) and torch.equal(ga3, ga)
 
 
 def test_sinkhorn_dense_agrees_with_small_set_kernel(gpu_device):

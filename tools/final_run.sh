@@ -8,7 +8,7 @@ QUICK=${2:-}
 mkdir -p $O
 cd $R
 if [ -z "$QUICK" ]; then
-  timeout 3000 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/pytest_gpu.txt
+  (hostname; rocm-smi --showuniqueid 2>/dev/null | grep -i unique) > $O/box.txt 2>&1; timeout 3000 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/pytest_gpu.txt
   grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 >> $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 fi
