@@ -193,6 +193,45 @@ __device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float g
   sh = __builtin_fmaf(-mean, sc, beta);
 }
 
+// Train-mode BatchNorm forward, per-channel scale / shift from the batch sums.  Reading an accumulator is two 64-bit
+// integer -> float conversions (~25 instructions); a thread that converted the sums of its own 8 channels spent more on
+// that than on its four granules (+1.5 us on 6-us launches).  One conversion per channel and WORKGROUP instead: thread c
+// converts channel c and leaves {scale, shift} in LDS; block 0 also writes the saved / running statistics from there.
+constexpr int kBnTabC = 1024;
+template <int EG>
+__device__ __forceinline__ void bn_fwd_scale_shift(
+    float* s_tab, int C, int cg, float inv_rows, const acc_t* __restrict__ sum, const acc_t* __restrict__ sumsq,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float unbias,
+    float* running_mean, float* running_var, float* save_mean, float* save_invstd, float (&sc)[EG], float (&sh)[EG]) {
+  const bool tab = C <= kBnTabC;
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    if (!tab && blockIdx.x != 0) break;
+    const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
+    const float var = fmaxf(det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m, 0.f);
+    const float is = rsqrtf(var + eps);
+    if (tab) bn_scale_shift(m, is, gamma[c], beta[c], s_tab[c], s_tab[kBnTabC + c]);
+    if (blockIdx.x == 0) {
+      if (save_mean) save_mean[c] = m;
+      if (save_invstd) save_invstd[c] = is;
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
+    }
+  }
+  if (tab) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EG; ++e) { sc[e] = s_tab[cg * EG + e]; sh[e] = s_tab[kBnTabC + cg * EG + e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EG; ++e) {
+      const int c = cg * EG + e;
+      const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
+      const float var = fmaxf(det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m, 0.f);
+      bn_scale_shift(m, rsqrtf(var + eps), gamma[c], beta[c], sc[e], sh[e]);
+    }
+  }
+}
+
 // y = act(gamma * (x - mean) * invstd + beta), mean/var from the batch sums.
 template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
@@ -204,25 +243,9 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
   float sc[EG], sh[EG];
-#pragma unroll
-  for (int e = 0; e < EG; ++e) {
-    const int c = cg * EG + e;
-    const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
-    float var = det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m;
-    var = fmaxf(var, 0.f);
-    const float is = rsqrtf(var + eps);
-    bn_scale_shift(m, is, gamma[c], beta[c], sc[e], sh[e]);
-  }
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += kThreads) {
-      const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
-      float var = fmaxf(det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m, 0.f);
-      if (save_mean) save_mean[c] = m;
-      if (save_invstd) save_invstd[c] = rsqrtf(var + eps);
-      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
-    }
-  }
+  __shared__ float s_tab[2 * kBnTabC];
+  bn_fwd_scale_shift<EG>(s_tab, C, cg, inv_rows, sum, sumsq, gamma, beta, eps, momentum, unbias, running_mean,
+                         running_var, save_mean, save_invstd, sc, sh);
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
 #pragma unroll 4
   for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
@@ -389,24 +412,9 @@ __global__ __launch_bounds__(kThreads) void bn_pool_fwd_kernel(
   const int cgs = C / EG;
   const int cg = threadIdx.x % cgs;
   float sc[EG], sh[EG];
-#pragma unroll
-  for (int e = 0; e < EG; ++e) {
-    const int c = cg * EG + e;
-    const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
-    float var = det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m;
-    var = fmaxf(var, 0.f);
-    bn_scale_shift(m, rsqrtf(var + eps), gamma[c], beta[c], sc[e], sh[e]);
-  }
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += kThreads) {
-      const float m = det_read<KD6D_DET_ACT>(sum + 2 * c) * inv_rows;
-      float var = fmaxf(det_read<KD6D_DET_ACT>(sumsq + 2 * c) * inv_rows - m * m, 0.f);
-      if (save_mean) save_mean[c] = m;
-      if (save_invstd) save_invstd[c] = rsqrtf(var + eps);
-      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
-    }
-  }
+  __shared__ float s_tab[2 * kBnTabC];
+  bn_fwd_scale_shift<EG>(s_tab, C, cg, inv_rows, sum, sumsq, gamma, beta, eps, momentum, unbias, running_mean,
+                         running_var, save_mean, save_invstd, sc, sh);
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
   for (int item = blockIdx.x * kThreads + threadIdx.x; item < items; item += gridDim.x * kThreads) {
     const PoolWin w = pool_window(item, H, W, cgs);
@@ -869,25 +877,36 @@ __global__ __launch_bounds__(kThreads) void gn_relu_fwd_kernel(
 #pragma unroll
   for (int e = 0; e < EG; ++e) { ga[e] = gamma[cg * EG + e]; be[e] = beta[cg * EG + e]; }
   u32x4_t* yg = reinterpret_cast<u32x4_t*>(y);
+  // A workgroup takes a CONTIGUOUS range of granules, kThreads at a time, so a thread's consecutive granules lie
+  // kThreads / cgs rows apart and almost always in the same (level, image): the statistics of its one or two groups are
+  // converted from their accumulators when that key changes, not per granule (4 conversions of ~25 instructions each
+  // per granule made this kernel 1.7 us slower per launch than with fp32 statistics).
+  const long long per = (((ngran + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads) * kThreads;
+  const long long g_begin = (long long)blockIdx.x * per;
+  const long long g_end = g_begin + per < ngran ? g_begin + per : ngran;
+  const int g0 = (cg * EG) / cpg;
+  const bool two = (cpg % EG) != 0;       // a granule may touch two groups (cpg >= EG / 2); one when groups are whole granules
+  int key = -1;
+  float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f;
 #pragma unroll 4
-  for (long long g = (long long)blockIdx.x * kThreads + threadIdx.x; g < ngran;
-       g += (long long)gridDim.x * kThreads) {
+  for (long long g = g_begin + threadIdx.x; g < g_end; g += kThreads) {
     const long long row = g / cgs;
     int seg, b, hw;
     gn_locate(gm, row, seg, b, hw);
-    const float inv_n = 1.f / ((float)hw * (float)cpg);
-    const acc_t* st = stats + ((size_t)(seg * gm.batch + b) * G) * 4;
     float v[EG];
     load_x<TX, EG>(x, g, v);
-    constexpr int NG = 2;                 // a granule touches at most 2 groups (cpg >= EG/2)
-    const int g0 = (cg * EG) / cpg;
-    float mu[NG], rs[NG];
-#pragma unroll
-    for (int k = 0; k < NG; ++k) gn_mean_rstd(st + min(g0 + k, G - 1) * 4, inv_n, eps, mu[k], rs[k]);
+    const int k_sb = seg * gm.batch + b;
+    if (k_sb != key) {
+      key = k_sb;
+      const float inv_n = 1.f / ((float)hw * (float)cpg);
+      const acc_t* st = stats + ((size_t)k_sb * G) * 4;
+      gn_mean_rstd(st + g0 * 4, inv_n, eps, mu0, rs0);
+      if (two) gn_mean_rstd(st + min(g0 + 1, G - 1) * 4, inv_n, eps, mu1, rs1);
+    }
 #pragma unroll
     for (int e = 0; e < EG; ++e) {
-      const int k = (cg * EG + e) / cpg - g0;
-      const float t = (v[e] - (k ? mu[1] : mu[0])) * (k ? rs[1] : rs[0]) * ga[e] + be[e];
+      const bool k = two && (cg * EG + e) / cpg != g0;
+      const float t = (v[e] - (k ? mu1 : mu0)) * (k ? rs1 : rs0) * ga[e] + be[e];
       v[e] = fmaxf(t, 0.f);
     }
     yg[g] = f32_to_granule<T>(v);
@@ -978,7 +997,9 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_reduce_kernel(
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     ga[e] = gamma[c]; be[e] = beta[c];
-    gn_mean_rstd(stats + (sb + c / cpg) * 4, inv_n, eps, mu[e], rs[e]);
+    // (one conversion per group: the channels of a granule share one or two)
+    if (e == 0 || c % cpg == 0) gn_mean_rstd(stats + (sb + c / cpg) * 4, inv_n, eps, mu[e], rs[e]);
+    else { mu[e] = mu[e ? e - 1 : 0]; rs[e] = rs[e ? e - 1 : 0]; }
   }
   float a_dy[EG], a_dyx[EG];
 #pragma unroll
@@ -1042,7 +1063,9 @@ __device__ __forceinline__ void gn_relu_bwd_onepass_body(
   for (int e = 0; e < EG; ++e) {
     const int c = cg * EG + e;
     ga[e] = gamma[c]; be[e] = beta[c];
-    gn_mean_rstd(stats + (sb + c / cpg) * 4, inv_n, eps, mu[e], rs[e]);
+    // (one conversion per group: the channels of a granule share one or two)
+    if (e == 0 || c % cpg == 0) gn_mean_rstd(stats + (sb + c / cpg) * 4, inv_n, eps, mu[e], rs[e]);
+    else { mu[e] = mu[e ? e - 1 : 0]; rs[e] = rs[e ? e - 1 : 0]; }
   }
   float a_dy[EG], a_dyx[EG];
 #pragma unroll
@@ -1165,6 +1188,8 @@ __global__ __launch_bounds__(kThreads) void gn_relu_bwd_apply_kernel(
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int gi = min(g0 + k, G - 1);
+      mu[k] = rs[k] = k1[k] = k2[k] = 0.f;
+      if (k && (cpg % EG) == 0) continue;         // groups are whole granules: the second one is never read
       gn_mean_rstd(stats + (sb + gi) * 4, inv_n, eps, mu[k], rs[k]);
       k1[k] = det_read<KD6D_DET_GRAD>(gsum + (sb + gi) * 4) * inv_n;
       k2[k] = det_read<KD6D_DET_GRAD>(gsum + (sb + gi) * 4 + 2) * inv_n;

@@ -161,7 +161,9 @@ TOL = {
     # fp32, round 4 (fixed-point accumulators instead of fp32 atomics: the sums are also more ACCURATE): losses equal to
     # 5 digits, per-tensor norm worst 3.3e-3 / 3.1e-3 / 2.4e-3 (config 2 / config 4 / S640; 1.6e-2 with atomics), tensors
     # >= 1024 elements 2.6e-4 ... 4.3e-4, update-sign agreement 0.99999
-    "fp32": dict(loss=1e-3, kd=2e-3, gn=5e-3, worst=1e-2, worst1k=2e-3, wmean=1e-3, cos=1e-4, loss2=2e-2, sign=0.995),
+    # Bounds are 5-20x the measured numbers (losses <= 5e-7, KD 6e-7, global norm <= 1.3e-5, norm-weighted mean 4e-6,
+    # second-step losses <= 2e-5): a deterministic path has no run-to-run spread to leave room for.
+    "fp32": dict(loss=1e-5, kd=1e-5, gn=1e-4, worst=1e-2, worst1k=1e-3, wmean=1e-4, cos=1e-5, loss2=3e-4, sign=0.999),
     # bf16 against the bf16-storage emulation, round 4: EVERY one of the 150 gradient tensors is bounded (rounds 2-3 set the
     # tensors aside that did not reproduce between runs; two executions are bitwise equal now, so this table is
     # deterministic -- the same numbers on every box).  Measured, config 2 / grouped config 2 / config 4 / S640
