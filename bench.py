@@ -618,14 +618,19 @@ def bench_dense(args, out_fd):
         last_on = eps_list[-1] >= thr
         grad_on = last_on and ops.get_option("sinkhorn.dense_mfma") != 3
         n_mfma = (4 * (1 + sum(1 for e in eps_list if e >= thr)) + (2 if last_on else 0) + (2 if grad_on else 0)) if on_mfma else 0
-        n_diff = passes - n_mfma
-        mfma_flop = (n_mfma * 6 * 2 * D + (2 * 4 * 2 * D if (on_mfma and grad_on) else 0)) * float(N) * float(M)
+        # below the rule (round 4): SCREENED passes -- the same six products give approximate exponents, one maximum chain per
+        # tile decides which pairs can contribute at all, only those are evaluated in the difference form
+        # (dense_softmin_screen_kernel; option sinkhorn.dense_screen = 0: every pair in the difference form)
+        screened = on_mfma and ops.get_option("sinkhorn.dense_screen") != 0
+        n_screen = (4 * sum(1 for e in eps_list if e < thr) + (0 if last_on else 4)) if screened else 0
+        n_diff = passes - n_mfma - n_screen
+        mfma_flop = ((n_mfma + n_screen) * 6 * 2 * D + (2 * 4 * 2 * D if (on_mfma and grad_on) else 0)) * float(N) * float(M)
         laneops = n_diff * float(N) * float(M) * (2 * D + 8)
         peak = PEAK_F32 / 2                         # lane-ops/s of the fp32 vector pipes (157.3 TFLOP/s counts FMA twice)
         # ALGORITHMIC work: 2 D flops of the inner product + ~8 of the exp / running logsumexp per pair
         algo_flop = pairs * (2 * D + 8)
         results.append({"blur": blur, "diameter": diam, "eps_steps": n_eps, "softmin_passes": passes,
-                        "passes_matrix_pipe": n_mfma, "passes_difference_form": n_diff,
+                        "passes_matrix_pipe": n_mfma, "passes_screened": n_screen, "passes_difference_form": n_diff,
                         "ms_per_image": ms, "images_per_s": world * 1e3 / ms, "pairs_per_s": pairs / (ms * 1e-3),
                         "algorithmic_tflops": algo_flop / (ms * 1e-3) / 1e12,
                         "issued_mfma_tflops_over_whole_time": mfma_flop / (ms * 1e-3) / 1e12,
@@ -646,19 +651,22 @@ def bench_dense(args, out_fd):
                                % (N, D, head["blur"], kd["SCALING"], kd["REACH"]), "parallelism": "replicas x%d" % world},
         # roofline.frac counts ALGORITHMIC flops (40 per pair at D = 16) against the roof SURVEY.md 8(d) names for this
         # path, the fp32 vector pipe (157.3 TFLOP/s): a fraction above what the difference form can reach means the bound was
-        # sidestepped by moving the inner products to the matrix pipe, not beaten.  What the matrix pipe ISSUES for it (192 FLOP
-        # per pair: six bf16 MFMAs on three-way split fp32 operands) is kept under its own key, against its own peak.
+        # sidestepped -- the inner products moved to the matrix pipe and, in the screened passes, the exact evaluation of the
+        # pairs that cannot contribute skipped -- not beaten.  What the matrix pipe ISSUES for it (192 FLOP per pair: six bf16
+        # MFMAs on three-way split fp32 operands) is kept under its own key, against its own peak.
         "roofline": {"bound": "valu-fp32 (SURVEY.md 8(d): online logsumexp, costs never stored)",
                      "kernel": "sinkhorn_dense: dense_softmin_mfma_kernel / dense_softmin_mfma_grad_kernel (matrix-pipe passes), "
-                               "dense_softmin_kernel (difference form)",
+                               "dense_softmin_screen_kernel (small-eps passes: matrix-pipe screen + exact difference form for the "
+                               "pairs that pass), dense_softmin_kernel (difference form for every pair)",
                      "achieved": head["algorithmic_tflops"], "peak": PEAK_F32 / 1e12, "unit": "TFLOP/s",
                      "frac": head["algorithmic_tflops"] * 1e12 / PEAK_F32, "traffic": None,
                      "basis": "(2 D + 8) = 40 FLOP per (row, column) pair x %d softmin passes x N M pairs / WALL time of one image; "
-                              "%d passes on the matrix pipe, %d in the difference form" % (head["softmin_passes"],
-                                                                                         head["passes_matrix_pipe"], head["passes_difference_form"]),
+                              "%d passes on the matrix pipe, %d screened on it (exact terms only for pairs within 40 + the error "
+                              "bound of a row's running maximum), %d with every pair in the difference form"
+                              % (head["softmin_passes"], head["passes_matrix_pipe"], head["passes_screened"], head["passes_difference_form"]),
                      "issued_mfma": {"achieved": head["issued_mfma_tflops_over_whole_time"], "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                      "frac": head["issued_mfma_tflops_over_whole_time"] * 1e12 / PEAK_BF16,
-                                     "basis": "192 FLOP per pair of the matrix-pipe passes (+ 128 of the two gradient-carrying ones) / wall time"},
+                                     "basis": "192 FLOP per pair of the matrix-pipe and screened passes (+ 128 of the two gradient-carrying ones on the matrix pipe) / wall time"},
                      "algorithmic_frac_of_bf16_mfma_peak": head["algorithmic_tflops"] * 1e12 / PEAK_BF16},
         "all_blurs": results, "finite": all(r_["finite"] for r_ in results)}))
 
@@ -705,7 +713,7 @@ def secondary_runs(args):
                              roofline={k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")})
                 if "all_blurs" in d:
                     entry["all_blurs"] = [{k: b[k] for k in ("blur", "ms_per_image", "images_per_s", "passes_matrix_pipe",
-                                                               "passes_difference_form")} for b in d["all_blurs"]]
+                                                               "passes_screened", "passes_difference_form")} for b in d["all_blurs"]]
         except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
             entry.update(ok=False, error=repr(e)[:400])
         entry["wall_s"] = time.perf_counter() - t0

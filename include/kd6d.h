@@ -280,6 +280,9 @@ int kd6d_device_cu_count(void);
  *                  eps >= 1.5e-4 diameter^2 | 0 never | 2 every pass (error studies) | 3 as 1, the gradient-carrying
  *                  softmins in the difference form
  *   conv.smallc_wmax  widest map the resident-patch kernel (3x3, 8-32 input channels) takes: 640 | 256 (rounds 1-2)
+ *   sinkhorn.dense_screen  dense OT, D = 16, passes with eps below the matrix-pipe rule: 1 approximate exponents on the
+ *                  matrix pipe screen the pairs, those within 40 (+ the error bound) of a row's running maximum are
+ *                  evaluated exactly in the difference form | 0 every pair in the difference form
  * Unknown names return KD6D_ERR_ARG. */
 /* Context: the library's mutable state -- the option table, the pair bracket of kd6d_conv2d_pair_begin/_end and the
  * counter of in-kernel barrier waits that gave up -- lives in a kd6d_ctx.  Every entry point of this header acts on the

@@ -55,6 +55,8 @@ enum Kd6dOption {
                                  // | 3 as 1, but the gradient-carrying softmins of the last extrapolation keep the difference form
   KD6D_OPT_CONV_HALO_WIDE,     // 1 | 0: maps 65 ... 80 wide (480 x 640 full frames) stay off the halo-patch kernel
   KD6D_OPT_CONV_SMALLC_WMAX,   // widest map the resident-patch kernel takes (640; 256 = the limit of rounds 1-2)
+  KD6D_OPT_SINKHORN_DENSE_SCREEN,  // dense OT, D = 16, passes below the matrix-pipe rule: 1 screened on the matrix pipe, exact pairs in the
+                                   // difference form | 0 every pair in the difference form
   KD6D_OPT_COUNT
 };
 long long kd6d_opt(int id);          // of the calling thread's current context

@@ -42,6 +42,7 @@ struct DenseArgs {
   int mode;                                // 0: init (h = log w), 1: symmetrised update, 2: last extrapolation
   float eps, lam;                          // epsilon, 1/(1+eps/rho) (1 if balanced)
   float* grad_xx; float* grad_xy;          // mode 2: softmax-weighted sums of (x_i - c_j), (N,D) each
+  float screen_th;                         // dense_softmin_screen_kernel: exponent distance from the running maximum beyond which a pair is dropped
   int which[4];                            // the softmins of this launch, one per blockIdx.y: 0 a_x (x<-x), 1 b_y (y<-y),
                                            // 2 a_y (y<-x), 3 b_x (x<-y)
 };
@@ -456,6 +457,241 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
 }
 
 // ---------------------------------------------------------------------------
+// Small epsilon (below the matrix-pipe rule above): SCREENING.  The expansion's value is only good to
+// ~k2 2^-22 (|r|^2 + |c|^2) in the exponent -- +-1 at eps = 1e-6 -- so it cannot BE the softmin's term; but a pair whose
+// approximate exponent lies more than TH = 40 + (that error bound) below the running maximum of its row contributes less
+// than 2^-40 of the sum whatever its exact value, and at small epsilon that is almost every pair: exponents are spread
+// over k2 |r - c|^2 ~ 10^3 ... 10^6 units.  So: the six-product block on the matrix pipe as above, ONE maximum chain and
+// one compare per lane and tile on the vector pipe, and only lanes that hold a pair within TH of their running maximum
+// evaluate those pairs EXACTLY -- the difference form of dense_softmin_kernel, from raw fp32 coordinates staged beside
+// the pieces: the same arithmetic, so the result equals the difference form's up to the neglected < 2^-40 terms.  The
+// (max, sum[, gradient sums]) of the exact values are what the kernel keeps; the approximate values never enter them.
+// A lane's own maximum is always within TH of itself, so every lane with a finite column has a term.
+// GRAD: the softmax-weighted difference sums of the last extrapolation (rows of x only), as dense_softmin_kernel<.., true>.
+// ---------------------------------------------------------------------------
+template <bool GRAD>
+__global__ __launch_bounds__(256) void dense_softmin_screen_kernel(const DenseArgs a, const DenseSplit sp) {
+  constexpr int D = 16;
+  __shared__ __attribute__((aligned(16))) char cs[2][kMTile * kMPitchB];
+  __shared__ __attribute__((aligned(16))) float raw[2][kMTile * D];
+  __shared__ __attribute__((aligned(16))) float hs[2][kMTile];       // approximate: h log2e - k2 |c - centre|^2
+  __shared__ float hx[2][kMTile];                                     // exact: h log2e
+  __shared__ float mrg[kMRows * (GRAD ? 2 + D : 2)];
+  const int which = a.which[blockIdx.y];
+  const bool rows_x = (which == 0 || which == 3);
+  const bool cols_x = (which == 0 || which == 2);
+  const char* Rs = rows_x ? sp.xs : sp.ys;
+  const char* Cs = cols_x ? sp.xs : sp.ys;
+  const float* Cn2 = cols_x ? sp.xn2 : sp.yn2;
+  const float* Rraw = rows_x ? a.x : a.y;
+  const float* Craw = cols_x ? a.x : a.y;
+  const int nr = rows_x ? a.N : a.M;
+  const int nc = cols_x ? a.N : a.M;
+  const float* lw = cols_x ? a.la : a.lb;
+  const int cpot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_bx(a) : off_ay(a);
+  const int opot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_ay(a) : off_bx(a);
+  if (blockIdx.x * kMRows >= nr) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rgrp = wave & 1, chalf = wave >> 1, half = lane >> 5;
+  const int lrow = rgrp * 32 + (lane & 31);
+  const int row = blockIdx.x * kMRows + lrow;
+  const bool rok = row < nr;
+  const float inv_eps = 1.f / a.eps;
+  const float k2 = 0.5f * inv_eps * kLog2e;
+  bf16x8_t bh, bm_, bl;
+  {
+    const bf16x8_t* rp = reinterpret_cast<const bf16x8_t*>(Rs + (size_t)(rok ? row : 0) * kSplitBytes);
+    const bf16x8_t ph = rp[0 * 2 + half], pm = rp[1 * 2 + half], pl = rp[2 * 2 + half];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = rok ? ((float)ph[e] + (float)pm[e]) + (float)pl[e] : 0.f;
+      bf16_t h, m, l;
+      split3(2.f * k2 * v, h, m, l);
+      bh[e] = h; bm_[e] = m; bl[e] = l;
+    }
+  }
+  float r[D];
+#pragma unroll
+  for (int d4 = 0; d4 < D; d4 += 4) {
+    const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(Rraw + (size_t)(rok ? row : 0) * D + d4);
+    r[d4] = rv[0]; r[d4 + 1] = rv[1]; r[d4 + 2] = rv[2]; r[d4 + 3] = rv[3];
+  }
+
+  // staging as in dense_softmin_mfma_kernel, plus the raw coordinates: 128 x 64 bytes = 512 chunks of 16 B, two per thread
+  int ldst[3], scol[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + 256 * j;
+    scol[j] = i / 6;
+    ldst[j] = scol[j] * kMPitchB + (i - scol[j] * 6) * 16;
+  }
+  u32x4_t sv[3], rw[2];
+  float s_lw = 0.f, s_pot = 0.f, s_n2 = 0.f;
+  const bool with_pot = a.mode != 0;
+  auto fetch = [&](int c0) {
+    const char* g = Cs + (size_t)c0 * kSplitBytes + (size_t)tid * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      sv[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c0 + scol[j] < nc) sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * 4096);
+    }
+    const char* gr = reinterpret_cast<const char*>(Craw) + (size_t)c0 * (D * 4) + (size_t)tid * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rw[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c0 + (tid + 256 * j) / 4 < nc) rw[j] = *reinterpret_cast<const u32x4_t*>(gr + j * 4096);
+    }
+    if (tid < kMTile) {
+      const bool ok = c0 + tid < nc;
+      const int c = ok ? c0 + tid : 0;
+      s_lw = ok ? lw[c] : -INFINITY;
+      s_pot = with_pot ? a.pot_old[cpot + c] : 0.f;
+      s_n2 = Cn2[c];
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = sv[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4_t*>(&raw[buf][(tid + 256 * j) * 4]) = rw[j];
+    if (tid < kMTile) {
+      const float h = (s_lw + s_pot * inv_eps) * kLog2e;          // -inf for a padding column
+      hx[buf][tid] = h;
+      hs[buf][tid] = h - k2 * s_n2;
+    }
+  };
+  auto block = [&](int buf, int blk) {
+    f32x16_t acc;
+    const float* hb = &hs[buf][blk * 32];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(hb + 4 * half + 8 * u);
+      acc[4 * u + 0] = h4[0]; acc[4 * u + 1] = h4[1]; acc[4 * u + 2] = h4[2]; acc[4 * u + 3] = h4[3];
+    }
+    const char* col = &cs[buf][(blk * 32 + (lane & 31)) * kMPitchB + half * 16];
+    const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(col);
+    const bf16x8_t am = *reinterpret_cast<const bf16x8_t*>(col + 32);
+    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(col + 64);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm_, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm_, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
+  };
+
+  float mt = -1e30f;                       // running maximum of the APPROXIMATE exponents of this lane's columns
+  float m = -1e30f, s = 0.f;               // exact (max, sum) over the pairs that passed the screen
+  float g[GRAD ? D : 1];
+#pragma unroll
+  for (int d = 0; d < (GRAD ? D : 1); ++d) g[d] = 0.f;
+  const float th = a.screen_th;
+
+  // one pair, exactly: column `c` of the staged tile (the arithmetic of dense_softmin_kernel)
+  auto exact = [&](int buf, int c) {
+    const float* cr = &raw[buf][c * D];
+    float d2 = 0.f, dd[GRAD ? D : 1];
+#pragma unroll
+    for (int d4 = 0; d4 < D; d4 += 4) {
+      const f32x4_t cv = *reinterpret_cast<const f32x4_t*>(cr + d4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float df = r[d4 + e] - cv[e];
+        d2 += df * df;
+        if (GRAD) dd[d4 + e] = df;
+      }
+    }
+    const float v = hx[buf][c] - d2 * k2;
+    const float mn = fmaxf(m, v);
+    const float sc = __builtin_amdgcn_exp2f(m - mn), e = __builtin_amdgcn_exp2f(v - mn);
+    s = s * sc + e;
+    if (GRAD) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) g[d] = g[d] * sc + e * dd[d];
+    }
+    m = mn;
+  };
+
+  const int ntiles = (nc + kMTile - 1) / kMTile;
+  fetch(0);
+  put(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    fetch((t + 1 < ntiles ? t + 1 : t) * kMTile);
+    const f32x16_t acc0 = block(buf, 2 * chalf);
+    const f32x16_t acc1 = block(buf, 2 * chalf + 1);
+    float tm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tm = fmaxf(fmaxf(tm, acc0[2 * u]), acc0[2 * u + 1]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tm = fmaxf(fmaxf(tm, acc1[2 * u]), acc1[2 * u + 1]);
+    mt = fmaxf(mt, tm);
+    const float thr = mt - th;
+    if (tm >= thr) {                       // rare at small epsilon; lanes diverge here
+      unsigned mask = 0u;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) mask |= (acc0[u] >= thr ? 1u : 0u) << u;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) mask |= (acc1[u] >= thr ? 1u : 0u) << (16 + u);
+      while (mask) {
+        const int u = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const int uu = u & 15;
+        // accumulator 4 q + r of a block <-> its column 8 q + 4 half + r
+        exact(buf, (2 * chalf + (u >> 4)) * 32 + 8 * (uu >> 2) + 4 * half + (uu & 3));
+      }
+    }
+    put(buf ^ 1);
+    __syncthreads();
+  }
+  // the two lanes of a row, then the two column halves (waves w and w + 2)
+  {
+    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
+    const float mn = fmaxf(m, m2);
+    const float c1 = __builtin_amdgcn_exp2f(m - mn), c2 = __builtin_amdgcn_exp2f(m2 - mn);
+    s = s * c1 + s2 * c2;
+    if (GRAD) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) g[d] = g[d] * c1 + __shfl_xor(g[d], 32, 64) * c2;
+    }
+    m = mn;
+  }
+  constexpr int MW = GRAD ? 2 + D : 2;
+  if (chalf == 1 && half == 0) {
+    mrg[MW * lrow] = m; mrg[MW * lrow + 1] = s;
+    if (GRAD) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) mrg[MW * lrow + 2 + d] = g[d];
+    }
+  }
+  __syncthreads();
+  if (chalf != 0 || half != 0 || !rok) return;
+  {
+    const float m2 = mrg[MW * lrow], s2 = mrg[MW * lrow + 1];
+    const float mn = fmaxf(m, m2);
+    const float c1 = __builtin_amdgcn_exp2f(m - mn), c2 = __builtin_amdgcn_exp2f(m2 - mn);
+    s = s * c1 + s2 * c2;
+    if (GRAD) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) g[d] = g[d] * c1 + mrg[MW * lrow + 2 + d] * c2;
+    }
+    m = mn;
+  }
+  const float lse = (m + __builtin_amdgcn_logf(s)) * kLn2;
+  const float val = -a.lam * a.eps * lse;
+  if (a.mode == 1) a.pot_new[opot + row] = 0.5f * (a.pot_old[opot + row] + val);
+  else a.pot_new[opot + row] = val;
+  if (GRAD) {
+    float* go = (which == 0 ? a.grad_xx : a.grad_xy) + (size_t)row * D;
+    const float inv_s = 1.f / s;
+#pragma unroll
+    for (int d = 0; d < D; ++d) go[d] = g[d] * inv_s;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The gradient-carrying softmins of the last extrapolation (rows of x: a_x over x, b_x over y) on the matrix pipe as well:
 // grad_i = sum_j w_ij (x_i - c_j) = x_i - (sum_j P_ij c_j) / (sum_j P_ij),  P_ij = exp2(v_ij - m_i)  (centred points: the
 // centre cancels).  The first product is the gradient-free kernel's; the second, O^T[piece * 16 + d][i] = sum_j C^T P^T, takes
@@ -844,11 +1080,17 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
     a.pot_old = cur; a.pot_new = nxt; a.mode = mode; a.eps = (float)eps;
     a.lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
     const bool mfma_ok = use_mfma && eps >= mfma_eps_min;
+    // below the rule: the matrix pipe screens, the difference form evaluates what passes (dense_softmin_screen_kernel).
+    // Threshold: 40 + twice the bound of the approximate exponent's error, k2 2^-21 S with S <= diameter^2 (centred points)
+    const bool screen_ok = use_mfma && !mfma_ok && kd6d_opt(KD6D_OPT_SINKHORN_DENSE_SCREEN) != 0;
+    a.screen_th = (float)(40.0 + (0.5 / eps) * 1.4426950408889634 * diameter * diameter * (1.0 / 1048576.0));
     auto set_which = [&](int w0, int w1, int w2, int w3) { a.which[0] = w0; a.which[1] = w1; a.which[2] = w2; a.which[3] = w3; };
     if (!grad) {
       set_which(0, 1, 2, 3);
       if (mfma_ok) {
         if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, sp);
+      } else if (screen_ok) {
+        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_screen_kernel<false>, grid_m, dim3(256), 0, st, a, sp);
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
       }
@@ -859,12 +1101,17 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
       if (mfma_ok && kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) != 3) {
         if constexpr (D == 16)
           hipLaunchKernelGGL(dense_softmin_mfma_grad_kernel, dim3((N + kMRows - 1) / kMRows, 2), dim3(256), 0, st, a, sp);
+      } else if (screen_ok) {
+        if constexpr (D == 16)
+          hipLaunchKernelGGL(dense_softmin_screen_kernel<true>, dim3((N + kMRows - 1) / kMRows, 2), dim3(256), 0, st, a, sp);
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, true, 4>), dim3((nmax + 127) / 128, 2), dim3(kThreadsD), 0, st, a);
       }
       set_which(1, 2, 0, 0);
       if (mfma_ok) {
         if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
+      } else if (screen_ok) {
+        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_screen_kernel<false>, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, false>), dim3(grid.x, 2), dim3(kThreadsD), 0, st, a);
       }

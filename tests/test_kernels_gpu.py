@@ -1400,6 +1400,36 @@ def test_sinkhorn_dense_gradient_as_second_product(gpu_device, N, M):
     assert not np.array_equal(res[1][1], res[3][1]), "option 1 did not take the matrix-pipe gradient kernel"
 
 
+@pytest.mark.parametrize("blur", [0.001, 0.01])
+@pytest.mark.parametrize("N,M", [(900, 777), (64, 130), (1000, 333), (129, 64)])
+def test_sinkhorn_dense_screened_small_epsilon_passes(gpu_device, N, M, blur):
+    """Passes with eps below the matrix-pipe rule (dense_softmin_screen_kernel): approximate exponents from the matrix
+    pipe decide WHICH pairs can contribute (within 40 + the error bound of the row's running maximum), those pairs are
+    evaluated exactly in the difference form.  Against the difference form over ALL pairs on the same inputs (option
+    sinkhorn.dense_screen = 0): the neglected terms are < 2^-40 each, so the loss agrees to fp32 rounding and the
+    gradients to 1e-4 of their scale; ragged row / column counts; gradient-free and gradient-carrying passes."""
+    ops = _ops()
+    D, reach = 16, 0.5
+    x, a, y, b = _dense_problem(N, M, D, 31, reach)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    res = {}
+    for screen in (1, 0):
+        _option("sinkhorn.dense_screen", screen)
+        loss, gx, ga = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=reach)
+        torch.cuda.synchronize()
+        res[screen] = (float(loss), gx.cpu().numpy(), ga.cpu().numpy())
+    assert np.isfinite(res[1][0]) and np.isfinite(res[1][1]).all() and np.isfinite(res[1][2]).all()
+    sg, sa = np.abs(res[0][1]).max(), np.abs(res[0][2]).max()
+    el = abs(res[1][0] - res[0][0]) / abs(res[0][0])
+    egx = float(np.abs(res[1][1] - res[0][1]).max() / sg)
+    ega = float(np.abs(res[1][2] - res[0][2]).max() / sa)
+    print("[dense OT screened %dx%d blur %g] loss %.2e, grad_x %.2e, grad_alpha %.2e of scale" % (N, M, blur, el, egx, ega))
+    # at eps = blur^2 = 1e-6 the softmax weights of near-tied columns move by ~10 % under the fp32 rounding of the potentials
+    # alone (1e-7 / eps = 0.1 in the exponent): two correct fp32 evaluations that add in another order differ by ~5e-4 of the
+    # gradient scale there (the difference form itself is 7e-4 from the fp64 oracle); at blur 0.01 that effect is 100x smaller
+    assert el <= 5e-6 and egx <= (2e-3 if blur < 0.005 else 1e-4) and ega <= 2e-5, (el, egx, ega)
+
+
 def test_context_isolates_options_pair_bracket_and_timeouts(gpu_device):
     """kd6d_ctx (include/kd6d.h): options, the pair bracket and the barrier-timeout counter belong to a context; entry
     points act on the calling thread's current one.  A second context must not see the first one's options or open
