@@ -109,7 +109,8 @@ def parse():
     p.add_argument("--tune", action="append", default=[],
                    help="schedule experiment, name=value: budget_div (CUs / this = the weight gradients' split-K budget), "
                         "group_wgs (workgroups of the grouped weight gradient), group_flush (head_end|fpn_end), streams "
-                        "(weight-gradient side streams)")
+                        "(weight-gradient side streams), fuse_stats_rows (largest layer whose BatchNorm sums come out of the "
+                        "convolution's epilogue instead of a colstats launch)")
     p.add_argument("--no-pipeline", action="store_true",
                    help="do not overlap the teacher forward of batch k+1 with the student step of batch k")
     p.add_argument("--cpu-steps", type=int, default=4)
@@ -339,6 +340,9 @@ def main():
     tune = dict(kv.split("=") for kv in args.tune)
     if "streams" in tune:
         GraphedKDStep.WGRAD_STREAMS = int(tune["streams"])
+    if "fuse_stats_rows" in tune:
+        from kd6d import engine as _engine
+        _engine.ConvBlock.FUSE_STATS_MAX_ROWS = int(tune["fuse_stats_rows"])
     if args.no_graph:
         gstep = None
     else:
@@ -354,7 +358,11 @@ def main():
         # shadow / dgrad packing the recorded kernels read are refreshed eagerly
         gstep.prepare(*batches[0])
         route = start_exchange()
-        student.net.prepare_weights(need_dgrad=True)
+        # everything the recorded kernels read that is derived from the weights, recomputed into the buffers the graphs
+        # hold (train_kd.py does the same through libs/train_libs.start_exchange_after_graphs; the teacher is built from
+        # the same seed on every rank here and is not broadcast, its refresh is the same code path all the same)
+        teacher.net.refresh_derived_in_place(need_dgrad=False)
+        student.net.refresh_derived_in_place(need_dgrad=True)
         torch.cuda.synchronize()
     if gstep is not None:
         if "budget_div" in tune:
