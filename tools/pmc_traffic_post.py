@@ -15,9 +15,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         n = r["Kernel_Name"]
         if "clip_adamw" in n:               # one optimizer launch closes every step of the invocation, whatever its
             steps_seen[c] += 1              # mix of warm-up, timed, probe and instrumented steps is
-        if "conv" not in n or "pack_dgrad" in n:
+        # the convolution family: every implicit-GEMM kernel, the split-K finalize, the grouped weight gradient with its
+        # reduce, and (round 4) the launch that sums the weight-gradient slabs -- rounds 1-3 matched on "conv" alone and
+        # left the grouped weight gradient and the finalize launches out
+        if not ("conv" in n or "wgrad_group" in n or "splitk_finalize" in n or "grad_acc_resolve" in n) or "pack_dgrad" in n:
             continue
-        key = "smallc" if "smallc" in n else "halo" if "halo" in n else "glds" if "glds" in n else "wgrad" if "wgrad" in n else "splitk_finalize" if "finalize" in n else "igemm"
+        key = ("smallc" if "smallc" in n else "halo" if "halo" in n else "glds" if "glds" in n
+               else "wgrad_group" if "wgrad_group" in n else "wgrad_resolve" if "grad_acc_resolve" in n
+               else "wgrad" if "wgrad" in n else "splitk_finalize" if "finalize" in n else "igemm")
         per[key][0] += 1
         per[key][1] += float(r["Counter_Value"])
     out[c] = {k: {"launches": v[0], "counter_sum": v[1]} for k, v in per.items()}
