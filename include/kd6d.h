@@ -283,6 +283,8 @@ int kd6d_device_cu_count(void);
  *   sinkhorn.dense_screen  dense OT, D = 16, passes with eps below the matrix-pipe rule: 1 approximate exponents on the
  *                  matrix pipe screen the pairs, those within 40 (+ the error bound) of a row's running maximum are
  *                  evaluated exactly in the difference form | 0 every pair in the difference form
+ *   sinkhorn.dense_rows  rows per workgroup of the dense matrix-pipe softmins (each workgroup streams all columns through
+ *                  LDS): -1 = 128 from 8192 rows up, 64 below | 64 | 128
  * Unknown names return KD6D_ERR_ARG. */
 /* Context: the library's mutable state -- the option table, the pair bracket of kd6d_conv2d_pair_begin/_end and the
  * counter of in-kernel barrier waits that gave up -- lives in a kd6d_ctx.  Every entry point of this header acts on the

@@ -57,6 +57,7 @@ enum Kd6dOption {
   KD6D_OPT_CONV_SMALLC_WMAX,   // widest map the resident-patch kernel takes (640; 256 = the limit of rounds 1-2)
   KD6D_OPT_SINKHORN_DENSE_SCREEN,  // dense OT, D = 16, passes below the matrix-pipe rule: 1 screened on the matrix pipe, exact pairs in the
                                    // difference form | 0 every pair in the difference form
+  KD6D_OPT_SINKHORN_DENSE_ROWS,    // rows per workgroup of the dense matrix-pipe softmins: -1 = 128 from 8192 rows up, else 64 | 64 | 128
   KD6D_OPT_COUNT
 };
 long long kd6d_opt(int id);          // of the calling thread's current context

@@ -25,7 +25,7 @@ const OptRow kOptRows[KD6D_OPT_COUNT] = {
     {"conv.halo", -1},  {"conv.smallc", -1},       {"conv.splitk", -1}, {"conv.tile", -1},     {"wgrad.small", -1},
     {"bn.onepass", 1},  {"bn.onepass_max", 65536}, {"gn.onepass", 1},   {"sinkhorn.lanes", 1},
     {"conv.halo_pairing", 1}, {"conv.fuse_norm", 3}, {"sinkhorn.dense_mfma", 1}, {"conv.halo_wide", 1},
-    {"conv.smallc_wmax", 640}, {"sinkhorn.dense_screen", 1},
+    {"conv.smallc_wmax", 640}, {"sinkhorn.dense_screen", 1}, {"sinkhorn.dense_rows", -1},
 };
 int opt_index(const char* name) {
   if (!name) return -1;

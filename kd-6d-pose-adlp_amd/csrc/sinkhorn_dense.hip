@@ -312,10 +312,12 @@ __device__ __forceinline__ void dense_lse_update(const f32x16_t& a0, const f32x1
   m = mn;
 }
 
-__global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs a, const DenseSplit sp) {
+template <int RG>
+__global__ __launch_bounds__(RG * 128) void dense_softmin_mfma_kernel(const DenseArgs a, const DenseSplit sp) {
   __shared__ __attribute__((aligned(16))) char cs[2][kMTile * kMPitchB];
   __shared__ __attribute__((aligned(16))) float hs[2][kMTile];
-  __shared__ float mrg[kMRows * 2];
+  constexpr int T = RG * 128, ROWS = RG * 32;        // threads, rows per workgroup: RG row groups x 2 column halves
+  __shared__ float mrg[ROWS * 2];
   const int which = a.which[blockIdx.y];
   const bool rows_x = (which == 0 || which == 3);
   const bool cols_x = (which == 0 || which == 2);
@@ -328,13 +330,13 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   const float* lw = cols_x ? a.la : a.lb;
   const int cpot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_bx(a) : off_ay(a);
   const int opot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_ay(a) : off_bx(a);
-  if (blockIdx.x * kMRows >= nr) return;
+  if (blockIdx.x * ROWS >= nr) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rgrp = wave & 1;                      // which 32 rows of the workgroup
-  const int chalf = wave >> 1;                    // which two of the four 32-column blocks of every tile
+  const int rgrp = wave % RG;                     // which 32 rows of the workgroup
+  const int chalf = wave / RG;                    // which two of the four 32-column blocks of every tile
   const int half = lane >> 5;                     // which 8 of the 16 dimensions this lane feeds
   const int lrow = rgrp * 32 + (lane & 31);
-  const int row = blockIdx.x * kMRows + lrow;
+  const int row = blockIdx.x * ROWS + lrow;
   const bool rok = row < nr;
   const float inv_eps = 1.f / a.eps;
   const float k2 = 0.5f * inv_eps * kLog2e;
@@ -358,35 +360,41 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
   // put() stores them behind it (the first version loaded, waited and stored chunk by chunk inside the tile loop: three
   // exposed L2 round trips per tile and workgroup).  A tile is 128 x 96 contiguous bytes = 768 chunks of 16 B, three per
   // thread; chunk i is piece q = i % 6 of column i / 6.  H_j comes from this launch's potentials (threads 0 .. 127).
-  int ldst[3], scol[3];
+  constexpr int NCH = (768 + T - 1) / T;            // 16-byte chunks of the pieces per thread (the last may be partial)
+  int ldst[NCH], scol[NCH];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int i = tid + 256 * j;
-    scol[j] = i / 6;
-    ldst[j] = scol[j] * kMPitchB + (i - scol[j] * 6) * 16;
+  for (int j = 0; j < NCH; ++j) {
+    const int i = tid + T * j;
+    scol[j] = i < 768 ? i / 6 : (1 << 28);          // a chunk beyond the tile: never in range
+    ldst[j] = i < 768 ? scol[j] * kMPitchB + (i - scol[j] * 6) * 16 : 0;
   }
-  u32x4_t sv[3];
-  float s_lw = 0.f, s_pot = 0.f, s_n2 = 0.f;      // the three inputs of H_j as loaded; combined in put(), behind the wait
+  // TWO tiles of loads are in flight: a tile's compute (~0.2 us per wave) is far shorter than an L2 / HBM round trip, and
+  // with one tile of look-ahead every iteration waited for its loads (285 us per launch against an 82-us matrix-pipe
+  // floor); the register sets alternate, the tile loop is unrolled by two so that both stay in registers
+  struct Stage { u32x4_t sv[NCH]; float lw, pot, n2; };    // lw, pot, n2: the three inputs of H_j as loaded; combined in put()
+  Stage stA, stB;
   const bool with_pot = a.mode != 0;
-  auto fetch = [&](int c0) {
+  auto fetch = [&](int c0, Stage& S) {                    // c0 >= nc: nothing is read, the tile is all padding
     const char* g = Cs + (size_t)c0 * kSplitBytes + (size_t)tid * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      sv[j] = u32x4_t{0u, 0u, 0u, 0u};
-      if (c0 + scol[j] < nc) sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * 4096);
+    for (int j = 0; j < NCH; ++j) {
+      S.sv[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c0 + scol[j] < nc) S.sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * (T * 16));
     }
+    S.lw = -INFINITY; S.pot = 0.f; S.n2 = 0.f;
     if (tid < kMTile) {
       const bool ok = c0 + tid < nc;
       const int c = ok ? c0 + tid : 0;
-      s_lw = ok ? lw[c] : -INFINITY;
-      s_pot = with_pot ? a.pot_old[cpot + c] : 0.f;
-      s_n2 = Cn2[c];
+      S.lw = ok ? lw[c] : -INFINITY;
+      S.pot = with_pot ? a.pot_old[cpot + c] : 0.f;
+      S.n2 = Cn2[c];
     }
   };
-  auto put = [&](int buf) {
+  auto put = [&](int buf, const Stage& S) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = sv[j];
-    if (tid < kMTile) hs[buf][tid] = (s_lw + s_pot * inv_eps) * kLog2e - k2 * s_n2;     // -inf for a padding column
+    for (int j = 0; j < NCH; ++j)
+      if (tid + T * j < 768) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = S.sv[j];
+    if (tid < kMTile) hs[buf][tid] = (S.lw + S.pot * inv_eps) * kLog2e - k2 * S.n2;     // -inf for a padding column
   };
 
   auto block = [&](int buf, int blk) {
@@ -413,25 +421,31 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
 
   float m = -1e30f, s = 0.f;
   const int ntiles = (nc + kMTile - 1) / kMTile;
-  fetch(0);
-  put(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    // (the last tile fetches itself again and stores into the buffer nobody reads any more: a loop body without
-    // branches is one scheduling region, which the two sched_barriers below need)
-    fetch((t + 1 < ntiles ? t + 1 : t) * kMTile);
+  // one tile: this wave's two blocks -- both MFMA chains are issued before the logsumexp, so the matrix pipe works on the
+  // second block while the VALU starts on the first; the stores of the tile after next (and their vmcnt wait) stay behind
+  // the logsumexp: the empty asm gives the pure arithmetic a position in the instruction stream the barrier can hold
+  auto tile = [&](int buf) {
     __builtin_amdgcn_sched_barrier(0);
-    // this wave's two blocks: both MFMA chains are issued before the logsumexp, so the matrix pipe works on the
-    // second block while the VALU starts on the first
     const f32x16_t acc0 = block(buf, 2 * chalf);
     const f32x16_t acc1 = block(buf, 2 * chalf + 1);
     dense_lse_update(acc0, acc1, m, s);
-    // the stores (and their vmcnt wait) stay behind the logsumexp: the empty asm gives the pure arithmetic above a
-    // position in the instruction stream that the barrier can hold
     __asm__ volatile("" : "+v"(m), "+v"(s));
     __builtin_amdgcn_sched_barrier(0);
-    put(buf ^ 1);                // every wave finished reading that buffer before the previous barrier
+  };
+  fetch(0, stA);
+  put(0, stA);
+  fetch(kMTile, stB);
+  __syncthreads();
+  // (an odd tile count runs one all-padding tile: H = -inf everywhere, no effect on (m, s); a loop body without branches
+  // is one scheduling region)
+  for (int t = 0; t < ntiles; t += 2) {
+    fetch((t + 2) * kMTile, stA);
+    tile(0);
+    put(1, stB);                 // tile t + 1; every wave finished reading buffer 1 before the previous barrier
+    __syncthreads();
+    fetch((t + 3) * kMTile, stB);
+    tile(1);
+    put(0, stA);                 // tile t + 2
     __syncthreads();
   }
   // the two lanes of a row, then the two column halves (waves w and w + 2)
@@ -469,14 +483,15 @@ __global__ __launch_bounds__(256) void dense_softmin_mfma_kernel(const DenseArgs
 // A lane's own maximum is always within TH of itself, so every lane with a finite column has a term.
 // GRAD: the softmax-weighted difference sums of the last extrapolation (rows of x only), as dense_softmin_kernel<.., true>.
 // ---------------------------------------------------------------------------
-template <bool GRAD>
-__global__ __launch_bounds__(256) void dense_softmin_screen_kernel(const DenseArgs a, const DenseSplit sp) {
+template <bool GRAD, int RG>
+__global__ __launch_bounds__(RG * 128) void dense_softmin_screen_kernel(const DenseArgs a, const DenseSplit sp) {
   constexpr int D = 16;
   __shared__ __attribute__((aligned(16))) char cs[2][kMTile * kMPitchB];
   __shared__ __attribute__((aligned(16))) float raw[2][kMTile * D];
   __shared__ __attribute__((aligned(16))) float hs[2][kMTile];       // approximate: h log2e - k2 |c - centre|^2
   __shared__ float hx[2][kMTile];                                     // exact: h log2e
-  __shared__ float mrg[kMRows * (GRAD ? 2 + D : 2)];
+  constexpr int T = RG * 128, ROWS = RG * 32;        // threads, rows per workgroup: RG row groups x 2 column halves
+  __shared__ float mrg[ROWS * (GRAD ? 2 + D : 2)];
   const int which = a.which[blockIdx.y];
   const bool rows_x = (which == 0 || which == 3);
   const bool cols_x = (which == 0 || which == 2);
@@ -490,11 +505,11 @@ __global__ __launch_bounds__(256) void dense_softmin_screen_kernel(const DenseAr
   const float* lw = cols_x ? a.la : a.lb;
   const int cpot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_bx(a) : off_ay(a);
   const int opot = which == 0 ? off_ax(a) : which == 1 ? off_by(a) : which == 2 ? off_ay(a) : off_bx(a);
-  if (blockIdx.x * kMRows >= nr) return;
+  if (blockIdx.x * ROWS >= nr) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rgrp = wave & 1, chalf = wave >> 1, half = lane >> 5;
+  const int rgrp = wave % RG, chalf = wave / RG, half = lane >> 5;
   const int lrow = rgrp * 32 + (lane & 31);
-  const int row = blockIdx.x * kMRows + lrow;
+  const int row = blockIdx.x * ROWS + lrow;
   const bool rok = row < nr;
   const float inv_eps = 1.f / a.eps;
   const float k2 = 0.5f * inv_eps * kLog2e;
@@ -518,46 +533,51 @@ __global__ __launch_bounds__(256) void dense_softmin_screen_kernel(const DenseAr
   }
 
   // staging as in dense_softmin_mfma_kernel, plus the raw coordinates: 128 x 64 bytes = 512 chunks of 16 B, two per thread
-  int ldst[3], scol[3];
+  constexpr int NCH = (768 + T - 1) / T;            // 16-byte chunks of the pieces per thread (the last may be partial)
+  int ldst[NCH], scol[NCH];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int i = tid + 256 * j;
-    scol[j] = i / 6;
-    ldst[j] = scol[j] * kMPitchB + (i - scol[j] * 6) * 16;
+  for (int j = 0; j < NCH; ++j) {
+    const int i = tid + T * j;
+    scol[j] = i < 768 ? i / 6 : (1 << 28);          // a chunk beyond the tile: never in range
+    ldst[j] = i < 768 ? scol[j] * kMPitchB + (i - scol[j] * 6) * 16 : 0;
   }
-  u32x4_t sv[3], rw[2];
-  float s_lw = 0.f, s_pot = 0.f, s_n2 = 0.f;
+  constexpr int NRW = (512 + T - 1) / T;
+  struct Stage { u32x4_t sv[NCH]; u32x4_t rw[NRW]; float lw, pot, n2; };     // two tiles of loads in flight, as above
+  Stage stA, stB;
   const bool with_pot = a.mode != 0;
-  auto fetch = [&](int c0) {
+  auto fetch = [&](int c0, Stage& S) {                    // c0 >= nc: nothing is read, the tile is all padding
     const char* g = Cs + (size_t)c0 * kSplitBytes + (size_t)tid * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      sv[j] = u32x4_t{0u, 0u, 0u, 0u};
-      if (c0 + scol[j] < nc) sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * 4096);
+    for (int j = 0; j < NCH; ++j) {
+      S.sv[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c0 + scol[j] < nc) S.sv[j] = *reinterpret_cast<const u32x4_t*>(g + j * (T * 16));
     }
     const char* gr = reinterpret_cast<const char*>(Craw) + (size_t)c0 * (D * 4) + (size_t)tid * 16;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      rw[j] = u32x4_t{0u, 0u, 0u, 0u};
-      if (c0 + (tid + 256 * j) / 4 < nc) rw[j] = *reinterpret_cast<const u32x4_t*>(gr + j * 4096);
+    for (int j = 0; j < NRW; ++j) {
+      S.rw[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (tid + T * j < 512 && c0 + (tid + T * j) / 4 < nc) S.rw[j] = *reinterpret_cast<const u32x4_t*>(gr + j * (T * 16));
     }
+    S.lw = -INFINITY; S.pot = 0.f; S.n2 = 0.f;
     if (tid < kMTile) {
       const bool ok = c0 + tid < nc;
       const int c = ok ? c0 + tid : 0;
-      s_lw = ok ? lw[c] : -INFINITY;
-      s_pot = with_pot ? a.pot_old[cpot + c] : 0.f;
-      s_n2 = Cn2[c];
+      S.lw = ok ? lw[c] : -INFINITY;
+      S.pot = with_pot ? a.pot_old[cpot + c] : 0.f;
+      S.n2 = Cn2[c];
     }
   };
-  auto put = [&](int buf) {
+  auto put = [&](int buf, const Stage& S) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = sv[j];
+    for (int j = 0; j < NCH; ++j)
+      if (tid + T * j < 768) *reinterpret_cast<u32x4_t*>(&cs[buf][ldst[j]]) = S.sv[j];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4_t*>(&raw[buf][(tid + 256 * j) * 4]) = rw[j];
+    for (int j = 0; j < NRW; ++j)
+      if (tid + T * j < 512) *reinterpret_cast<u32x4_t*>(&raw[buf][(tid + T * j) * 4]) = S.rw[j];
     if (tid < kMTile) {
-      const float h = (s_lw + s_pot * inv_eps) * kLog2e;          // -inf for a padding column
+      const float h = (S.lw + S.pot * inv_eps) * kLog2e;          // -inf for a padding column
       hx[buf][tid] = h;
-      hs[buf][tid] = h - k2 * s_n2;
+      hs[buf][tid] = h - k2 * S.n2;
     }
   };
   auto block = [&](int buf, int blk) {
@@ -614,12 +634,7 @@ __global__ __launch_bounds__(256) void dense_softmin_screen_kernel(const DenseAr
   };
 
   const int ntiles = (nc + kMTile - 1) / kMTile;
-  fetch(0);
-  put(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    fetch((t + 1 < ntiles ? t + 1 : t) * kMTile);
+  auto tile = [&](int buf) {
     const f32x16_t acc0 = block(buf, 2 * chalf);
     const f32x16_t acc1 = block(buf, 2 * chalf + 1);
     float tm = -INFINITY;
@@ -643,7 +658,19 @@ __global__ __launch_bounds__(256) void dense_softmin_screen_kernel(const DenseAr
         exact(buf, (2 * chalf + (u >> 4)) * 32 + 8 * (uu >> 2) + 4 * half + (uu & 3));
       }
     }
-    put(buf ^ 1);
+  };
+  fetch(0, stA);
+  put(0, stA);
+  fetch(kMTile, stB);
+  __syncthreads();
+  for (int t = 0; t < ntiles; t += 2) {        // (an odd tile count runs one all-padding tile: no column passes the screen)
+    fetch((t + 2) * kMTile, stA);
+    tile(0);
+    put(1, stB);
+    __syncthreads();
+    fetch((t + 3) * kMTile, stB);
+    tile(1);
+    put(0, stA);
     __syncthreads();
   }
   // the two lanes of a row, then the two column halves (waves w and w + 2)
@@ -1075,7 +1102,15 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
   // (header of dense_softmin_mfma_kernel): eps >= kMfmaEpsRel * diameter^2; option sinkhorn.dense_mfma: 0 = never,
   // 1 = by that rule, 2 = every gradient-free pass (tests: how wrong it gets)
   const double mfma_eps_min = kd6d_opt(KD6D_OPT_SINKHORN_DENSE_MFMA) == 2 ? 0.0 : kMfmaEpsRel * diameter * diameter;
-  const dim3 grid_m((nmax + kMRows - 1) / kMRows, 4);
+  // rows per workgroup of the matrix-pipe softmins: every workgroup streams ALL columns (108-172 bytes each) through LDS,
+  // so the launch moves (rows / rows-per-workgroup) x columns x bytes from L2 -- 1.8-2.9 GB at N = M = 16384 with 64
+  // rows, which is what bounds it (6-9 TB/s); 128 rows (8 waves) halve that.  Option sinkhorn.dense_rows: -1 = 128 from
+  // 8192 rows up | 64 | 128
+  const long long rows_opt = kd6d_opt(KD6D_OPT_SINKHORN_DENSE_ROWS);
+  const bool rg4 = rows_opt == 128 || (rows_opt != 64 && nmax >= 8192);
+  const int mrows = rg4 ? 128 : kMRows;
+  const dim3 grid_m((nmax + mrows - 1) / mrows, 4);
+  const dim3 block_m(rg4 ? 512 : 256);
   auto launch = [&](int mode, double eps, bool grad) {
     a.pot_old = cur; a.pot_new = nxt; a.mode = mode; a.eps = (float)eps;
     a.lam = rho > 0.0 ? (float)(1.0 / (1.0 + eps / rho)) : 1.f;
@@ -1088,9 +1123,15 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
     if (!grad) {
       set_which(0, 1, 2, 3);
       if (mfma_ok) {
-        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, grid_m, dim3(256), 0, st, a, sp);
+        if constexpr (D == 16) {
+          if (rg4) hipLaunchKernelGGL(dense_softmin_mfma_kernel<4>, grid_m, block_m, 0, st, a, sp);
+          else hipLaunchKernelGGL(dense_softmin_mfma_kernel<2>, grid_m, block_m, 0, st, a, sp);
+        }
       } else if (screen_ok) {
-        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_screen_kernel<false>, grid_m, dim3(256), 0, st, a, sp);
+        if constexpr (D == 16) {
+          if (rg4) hipLaunchKernelGGL((dense_softmin_screen_kernel<false, 4>), grid_m, block_m, 0, st, a, sp);
+          else hipLaunchKernelGGL((dense_softmin_screen_kernel<false, 2>), grid_m, block_m, 0, st, a, sp);
+        }
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, false>), grid, dim3(kThreadsD), 0, st, a);
       }
@@ -1103,15 +1144,22 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
           hipLaunchKernelGGL(dense_softmin_mfma_grad_kernel, dim3((N + kMRows - 1) / kMRows, 2), dim3(256), 0, st, a, sp);
       } else if (screen_ok) {
         if constexpr (D == 16)
-          hipLaunchKernelGGL(dense_softmin_screen_kernel<true>, dim3((N + kMRows - 1) / kMRows, 2), dim3(256), 0, st, a, sp);
+          if (rg4) hipLaunchKernelGGL((dense_softmin_screen_kernel<true, 4>), dim3((N + mrows - 1) / mrows, 2), block_m, 0, st, a, sp);
+          else hipLaunchKernelGGL((dense_softmin_screen_kernel<true, 2>), dim3((N + mrows - 1) / mrows, 2), block_m, 0, st, a, sp);
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, true, 4>), dim3((nmax + 127) / 128, 2), dim3(kThreadsD), 0, st, a);
       }
       set_which(1, 2, 0, 0);
       if (mfma_ok) {
-        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_mfma_kernel, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
+        if constexpr (D == 16) {
+          if (rg4) hipLaunchKernelGGL(dense_softmin_mfma_kernel<4>, dim3(grid_m.x, 2), block_m, 0, st, a, sp);
+          else hipLaunchKernelGGL(dense_softmin_mfma_kernel<2>, dim3(grid_m.x, 2), block_m, 0, st, a, sp);
+        }
       } else if (screen_ok) {
-        if constexpr (D == 16) hipLaunchKernelGGL(dense_softmin_screen_kernel<false>, dim3(grid_m.x, 2), dim3(256), 0, st, a, sp);
+        if constexpr (D == 16) {
+          if (rg4) hipLaunchKernelGGL((dense_softmin_screen_kernel<false, 4>), dim3(grid_m.x, 2), block_m, 0, st, a, sp);
+          else hipLaunchKernelGGL((dense_softmin_screen_kernel<false, 2>), dim3(grid_m.x, 2), block_m, 0, st, a, sp);
+        }
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, false>), dim3(grid.x, 2), dim3(kThreadsD), 0, st, a);
       }

@@ -58,7 +58,7 @@ def test_kernel_selection_options_table():
     defaults = {"conv.halo": -1, "conv.smallc": -1, "conv.splitk": -1, "conv.tile": -1, "wgrad.small": -1,
                 "bn.onepass": 1, "bn.onepass_max": 65536, "gn.onepass": 1, "sinkhorn.lanes": 1,
                 "conv.halo_pairing": 1, "conv.fuse_norm": 3, "sinkhorn.dense_mfma": 1, "conv.halo_wide": 1,
-                "conv.smallc_wmax": 640, "sinkhorn.dense_screen": 1}
+                "conv.smallc_wmax": 640, "sinkhorn.dense_screen": 1, "sinkhorn.dense_rows": -1}
     ops.lib.kd6d_reset_options()
     for k, v in defaults.items():
         assert ops.get_option(k) == v, k

@@ -1430,6 +1430,24 @@ def test_sinkhorn_dense_screened_small_epsilon_passes(gpu_device, N, M, blur):
     assert el <= 5e-6 and egx <= (2e-3 if blur < 0.005 else 1e-4) and ega <= 2e-5, (el, egx, ega)
 
 
+@pytest.mark.parametrize("blur", [0.05, 0.001])
+@pytest.mark.parametrize("N,M", [(900, 777), (130, 64), (257, 1000)])
+def test_sinkhorn_dense_rows_per_workgroup_do_not_change_the_result(gpu_device, N, M, blur):
+    """The matrix-pipe softmins with 64 or 128 rows per workgroup (option sinkhorn.dense_rows; 128 halves what a launch
+    pulls from L2 and is taken from 8192 rows up): a row's arithmetic does not depend on which workgroup holds it, so the
+    two give BITWISE the same loss and gradients -- matrix-pipe passes, screened passes and the gradient-carrying ones."""
+    ops = _ops()
+    x, a, y, b = _dense_problem(N, M, 16, 41, 0.5)
+    t = lambda v: torch.from_numpy(v).to(gpu_device)
+    res = {}
+    for rows in (64, 128):
+        _option("sinkhorn.dense_rows", rows)
+        res[rows] = ops.sinkhorn_dense(t(x), t(a), t(y), t(b), blur=blur, scaling=0.5, reach=0.5)
+        torch.cuda.synchronize()
+    for u, v in zip(res[64], res[128]):
+        assert bool(torch.isfinite(u).all()) and torch.equal(u, v)
+
+
 def test_context_isolates_options_pair_bracket_and_timeouts(gpu_device):
     """kd6d_ctx (include/kd6d.h): options, the pair bracket and the barrier-timeout counter belong to a context; entry
     points act on the calling thread's current one.  A second context must not see the first one's options or open
