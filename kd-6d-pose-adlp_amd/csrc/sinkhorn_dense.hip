@@ -1143,9 +1143,10 @@ int run_dense(const float* x, const float* alpha, const float* y, const float* b
         if constexpr (D == 16)
           hipLaunchKernelGGL(dense_softmin_mfma_grad_kernel, dim3((N + kMRows - 1) / kMRows, 2), dim3(256), 0, st, a, sp);
       } else if (screen_ok) {
-        if constexpr (D == 16)
+        if constexpr (D == 16) {
           if (rg4) hipLaunchKernelGGL((dense_softmin_screen_kernel<true, 4>), dim3((N + mrows - 1) / mrows, 2), block_m, 0, st, a, sp);
           else hipLaunchKernelGGL((dense_softmin_screen_kernel<true, 2>), dim3((N + mrows - 1) / mrows, 2), block_m, 0, st, a, sp);
+        }
       } else {
         hipLaunchKernelGGL((dense_softmin_kernel<D, true, 4>), dim3((nmax + 127) / 128, 2), dim3(kThreadsD), 0, st, a);
       }
