@@ -31,7 +31,7 @@ EXTRA_FLAGS = {"sinkhorn_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # losses.hip, sinkhorn.hip: no packed-fp32 instructions (v_pk_fma_f32 & co.) -- see DESIGN.md section 6,
                # "What made two executions differ": in these one-workgroup-per-image launches, running beside the other
                # network's convolutions, one HALF of a packed result occasionally came out as if its product were zero,
-               # for the last 16 lanes of a wave (tools/flake_hunt.py); with scalar fp32 instructions it does not happen
+               # for the last 16 lanes of a wave (tests/flake_hunt.py); with scalar fp32 instructions it does not happen
                "losses.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                "sinkhorn.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 

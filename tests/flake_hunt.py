@@ -3,7 +3,7 @@ first replay -- the tool that localises a run-to-run difference to the first ker
 that packed-fp32 instructions in the loss kernels occasionally return a wrong half beside the other network's
 convolutions: DESIGN.md section 6, kd-6d-pose-adlp_amd/build.py EXTRA_FLAGS.)
 
-    python tools/flake_hunt.py [--arch darknet_tiny] [--mixed] [--precision bf16] [--iters 300] [--group 1]
+    python tests/flake_hunt.py [--arch darknet_tiny] [--mixed] [--precision bf16] [--iters 300] [--group 1]
 
 The optimiser runs with lr = 0 and weight_decay = 0, so the parameters (and everything derived from them) do not move;
 the same batch is fed every call, so from the third call on every replay computes the same thing.  Compared per replay:
@@ -20,7 +20,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kd-6d-pose-adlp_amd"))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))     # test infrastructure: builds its networks like tests/test_step_gpu.py (seeded weights from oracle/)
 
 
 def main():

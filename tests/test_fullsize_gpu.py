@@ -545,7 +545,7 @@ def test_config1_plumbing_kd_weight_zero(gpu_device):
 
 @pytest.mark.parametrize("mode", ["pipeline", "grouped"])
 def test_replays_of_the_graphed_step_are_bitwise_equal(gpu_device, mode):
-    """tools/flake_hunt.py: the graphed step of config 4 (13 classes mixed, darknet_tiny, bf16) replayed 250 times on fixed
+    """tests/flake_hunt.py: the graphed step of config 4 (13 classes mixed, darknet_tiny, bf16) replayed 250 times on fixed
     weights (lr = 0), the teacher running beside the student as in training; after every replay the three losses, the
     gradient norm, the flat gradient bucket and every activation / scratch buffer of both networks must equal the first
     replay BIT FOR BIT.  This is the test that found the loss kernels' packed-fp32 instructions returning a wrong half for
@@ -553,7 +553,7 @@ def test_replays_of_the_graphed_step_are_bitwise_equal(gpu_device, mode):
     out, 0 of 12 000 replays differ."""
     import subprocess
     import sys
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "flake_hunt.py"), "--arch", "darknet_tiny", "--mixed", "--iters", "250",
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "flake_hunt.py"), "--arch", "darknet_tiny", "--mixed", "--iters", "250",
            "--stop", "1"] + (["--group", "3"] if mode == "grouped" else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

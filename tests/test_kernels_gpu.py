@@ -455,7 +455,7 @@ MIXED = [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, False)
 
 
 @pytest.mark.parametrize("dtype,xf32", MIXED)
-@pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64), (8, 300000), (16, 70001)])
+@pytest.mark.parametrize("C,rows", [(8, 1000), (16, 4096), (64, 777), (256, 300), (512, 64), (1024, 40), (8, 300000), (16, 70001)])
 @pytest.mark.parametrize("onepass", [False, True])
 def test_batchnorm_train_fwd_bwd(gpu_device, dtype, xf32, C, rows, onepass):
     """onepass: the backward as one launch whose workgroups meet at an in-kernel barrier (kd6d_bn_train_bwd with a
