@@ -356,14 +356,11 @@ def main():
         # graphs first, communicator second (GroupedTeacherKDStep.prepare): every graph is recorded from a sample batch
         # before the first RCCL communicator of the process exists; the parameters are broadcast afterwards and the bf16
         # shadow / dgrad packing the recorded kernels read are refreshed eagerly
-        gstep.prepare(*batches[0])
-        route = start_exchange()
-        # everything the recorded kernels read that is derived from the weights, recomputed into the buffers the graphs
-        # hold (train_kd.py does the same through libs/train_libs.start_exchange_after_graphs; the teacher is built from
-        # the same seed on every rank here and is not broadcast, its refresh is the same code path all the same)
-        teacher.net.refresh_derived_in_place(need_dgrad=False)
-        student.net.refresh_derived_in_place(need_dgrad=True)
-        torch.cuda.synchronize()
+        # the SAME function train_kd.py runs (and tests/test_distributed_cpu.py drives at world size 2 on gloo): prepare ->
+        # communicator -> broadcast of both networks' parameters and buffers -> in-place refresh of everything the recorded
+        # kernels read that is derived from them
+        from kd6d.libs.train_libs import start_exchange_after_graphs
+        route = start_exchange_after_graphs(gstep, teacher, student, batches[0], log=lambda m: print(m, file=sys.stderr))
     if gstep is not None:
         if "budget_div" in tune:
             student.net.wgrad_cu_budget = int(ops.device_cu_count() / float(tune["budget_div"]))
