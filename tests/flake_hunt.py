@@ -56,7 +56,8 @@ def main():
     BIAS = [1.0] + [-6.0] * 14
     teacher = build("darknet53", args.precision, 2, dev, BIAS).eval()
     student = build(args.arch, args.precision, 1, dev).train()
-    opt = FusedClipAdamW(student, lr=0.0, weight_decay=0.0, eps=1e-8, max_norm=1.0)
+    with_opt = "opt" in args.variant       # a real update every replay, state rewound before the next one
+    opt = FusedClipAdamW(student, lr=1e-3 if with_opt else 0.0, weight_decay=1e-4 if with_opt else 0.0, eps=1e-8, max_norm=1.0)
     levels = [(crop // 8 // (2 ** i),) * 2 for i in range(4)]
     cells = sum(h * w for h, w in levels)
     keys_ref = torch.rand(B * cells, generator=torch.Generator().manual_seed(17))
@@ -172,10 +173,28 @@ def main():
         print("graph written to", args.dot)
         return
 
+    st_ = student.net.store
+    state0 = None
+    if with_opt:
+        state0 = dict(params=st_.params.clone(), bufs=st_.bufs.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(),
+                      nbt=student._nbt.clone(), steps=opt.steps)
+
     def snapshot():
         out = {}
+        if with_opt:        # rewind: the same update from the same state every replay
+            st_.params.copy_(state0["params"]); st_.bufs.copy_(state0["bufs"])
+            opt.exp_avg.copy_(state0["m"]); opt.exp_avg_sq.copy_(state0["v"])
+            student._nbt.copy_(state0["nbt"]); opt.steps = state0["steps"]
+            student.net.refresh_derived_in_place(need_dgrad=True)
         ld = g(*batch)
         torch.cuda.synchronize()
+        if with_opt:
+            out["opt.params_after"] = st_.params.clone()
+            out["opt.exp_avg_after"] = opt.exp_avg.clone()
+            out["opt.exp_avg_sq_after"] = opt.exp_avg_sq.clone()
+            if st_.shadow is not None:
+                out["opt.shadow_after"] = st_.shadow.clone()
+            out["opt.bn_buffers_after"] = st_.bufs.clone()
         for k, v in ld.items():
             out["loss." + k] = v.detach().clone().reshape(-1)
         out["grad_norm"] = torch.tensor([float(opt.grad_norm())])
